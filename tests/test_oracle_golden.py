@@ -1,0 +1,110 @@
+"""The oracle (CPU restatement) against golden vectors produced by the reference's own code.
+
+Golden files: tests/golden/{sfc,padplan,attention,ptv3_tiny}.npz, written by
+tests/golden/make_golden.py in the build container (reference imported in place)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sfc, ptv3 as O
+from make_golden_cfg import TINY_CFG, ORDERS
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_sfc_codes_survey_appendix_a1():
+    # captured from default.py:9-24 in the survey session
+    gc = np.array([[684, 559, 629], [192, 835, 763], [707, 359, 9], [723, 277, 754], [804, 599, 70],
+                   [472, 600, 396], [314, 705, 486], [551, 87, 174]])
+    want = {
+        "z": [948411859, 448565787, 580453047, 716501166, 873341402, 364408384, 359581802, 539665406],
+        "z-trans": [944217573, 746361389, 341443383, 476901662, 840253932, 595095104, 599106652, 271696894],
+        "hilbert": [679408746, 319150882, 1038347237, 855888336, 554424821, 404320082, 416813811, 1013732344],
+        "hilbert-trans": [674082936, 927765046, 522841811, 390699204, 601067873, 978865122, 973232755, 515733064],
+    }
+    for o, w in want.items():
+        assert sfc.encode(gc, np.zeros(8, dtype=np.int64), 10, o).tolist() == w
+
+
+def test_sfc_golden(golden_dir):
+    g = _load(golden_dir, "sfc.npz")
+    for depth in (3, 5, 7, 10, 16):
+        for B in (1, 2, 8):
+            t = f"d{depth}_b{B}"
+            code, order, inverse, _ = sfc.serialization(g[t + "_grid_coord"], g[t + "_batch"], ORDERS, depth)
+            assert np.array_equal(code, g[t + "_code"])
+            assert np.array_equal(order, g[t + "_order"])
+            assert np.array_equal(inverse, g[t + "_inverse"])
+    assert sfc.serialized_depth(g["auto_grid_coord"]) == int(g["auto_depth"])
+    code, *_ = sfc.serialization(g["auto_grid_coord"], g["auto_batch"], ORDERS)
+    assert np.array_equal(code, g["auto_code"])
+
+
+def test_padplan_golden(golden_dir):
+    g = _load(golden_dir, "padplan.npz")
+    for i in range(int(g["n_cases"])):
+        off = g[f"c{i}_offset"]
+        K = sfc.patch_size_for(off, int(g[f"c{i}_pmax"]))
+        assert K == int(g[f"c{i}_K"])
+        pad, unpad, cu = sfc.pad_plan(off, K)
+        assert np.array_equal(pad, g[f"c{i}_pad"])
+        assert np.array_equal(unpad, g[f"c{i}_unpad"])
+        assert np.array_equal(cu, g[f"c{i}_cu"])
+
+
+def test_padplan_survey_appendix_a2():
+    pad, unpad, cu = sfc.pad_plan([5, 12], 4)
+    assert pad.tolist() == [0, 1, 2, 3, 4, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11, 8]
+    assert unpad.tolist() == [0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 13, 14]
+    assert cu.tolist() == [0, 4, 8, 12, 16]
+
+
+def test_attention_golden(golden_dir):
+    g = _load(golden_dir, "attention.npz")
+    for i in range(int(g["n_cases"])):
+        t = f"a{i}_"
+        C, H, pmax, oi, rpe, K = [int(v) for v in g[t + "cfg"]]
+        off = g[t + "offset"]
+        gc = g[t + "grid_coord"]
+        batch = np.repeat(np.arange(len(off)), np.diff(off, prepend=0))
+        code, order, inverse, _ = sfc.serialization(gc, batch, ORDERS)
+        assert sfc.patch_size_for(off, pmax) == K
+        pad, unpad, _ = sfc.pad_plan(off, K)
+        w = {k[len(t) + 2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(t + "w_")}
+        out = O.window_attention(
+            torch.from_numpy(g[t + "feat"]), w["qkv.weight"], w["qkv.bias"], w["proj.weight"], w["proj.bias"],
+            torch.from_numpy(order[oi]), torch.from_numpy(inverse[oi]), torch.from_numpy(pad),
+            torch.from_numpy(unpad), H, K,
+            rpe_table=w.get("rpe.rpe_table") if rpe else None,
+            grid_coord=torch.from_numpy(gc), patch_size_cfg=pmax)
+        ref = torch.from_numpy(g[t + "out"])
+        assert (out - ref).abs().max().item() < 2e-6, i
+        # the fused core (what the HIP kernel computes) reproduces the pre-projection tensor
+        core = O.window_attention_core(torch.from_numpy(g[t + "qkv"]), torch.from_numpy(order[oi]),
+                                       torch.from_numpy(inverse[oi]), torch.from_numpy(pad),
+                                       torch.from_numpy(unpad), H, K)
+        if not rpe:
+            proj = torch.nn.functional.linear(core, w["proj.weight"], w["proj.bias"])
+            assert (proj - ref).abs().max().item() < 2e-6, i
+
+
+def test_full_model_golden(golden_dir):
+    g = _load(golden_dir, "ptv3_tiny.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    data = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    orc = O.OffsetKeypointOracle(TINY_CFG, sd)
+    torch.manual_seed(int(g["shuffle_seed"]))
+    with torch.no_grad():
+        out = orc.forward(data)
+    tr = orc.backbone.trace
+    assert np.array_equal(tr["serialized_code"].numpy(), g["tap_serialized_code"])
+    assert np.array_equal(tr["serialized_order"].numpy(), g["tap_serialized_order"])
+    for k in ["embedding"] + [f"enc{s}" for s in range(5)] + [f"dec{s}" for s in range(4)]:
+        assert tr[k].shape == g["tap_" + k].shape
+        assert np.abs(tr[k].numpy() - g["tap_" + k]).max() < 2e-5, k
+    assert np.abs(out["pred"].numpy() - g["pred"]).max() < 2e-5
+    assert abs(out["loss"].item() - float(g["loss"])) < 1e-5
