@@ -1,0 +1,169 @@
+/* ptv3_hip.h -- C ABI of libptv3_hip.so: the MI355X (gfx950) kernels behind the PTv3
+ * serialized-window attention path of Pointcept-KeypointDetection.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only enqueues
+ *     work on that stream: no allocation, no synchronisation, graph-capturable;
+ *   - `dtype`: PTV3_F32 (0) = fp32 storage, exact-fp32 matrix-core math (parity mode);
+ *              PTV3_BF16 (1) = bf16 storage, bf16 MFMA with fp32 accumulate / fp32 softmax+norm;
+ *   - return value: 0 on success, non-zero on error (ptv3_last_error() gives the message);
+ *   - tensors are dense row-major.  "rows" of feature matrices are points.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository root).  The Python binding a maintainer adds is in INTEGRATION.md.
+ */
+#ifndef PTV3_HIP_H
+#define PTV3_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTV3_F32 0
+#define PTV3_BF16 1
+
+/* curve ids for ptv3_sfc_encode (pointcept/models/utils/serialization/default.py:9-24) */
+#define PTV3_ORDER_Z 0
+#define PTV3_ORDER_Z_TRANS 1
+#define PTV3_ORDER_HILBERT 2
+#define PTV3_ORDER_HILBERT_TRANS 3
+
+/* epilogue activation ids for ptv3_gemm */
+#define PTV3_ACT_NONE 0
+#define PTV3_ACT_GELU 1 /* erf form = torch.nn.GELU() default */
+#define PTV3_ACT_RELU 2
+
+const char* ptv3_last_error(void);
+int ptv3_version(void);
+
+/* ---- serialization ------------------------------------------------------------------------
+ * replaces encode() (utils/serialization/default.py:9-24), z_order.xyz2key (z_order.py:66-101)
+ * and hilbert.encode (hilbert.py:91-198): code[r][i] = batch[i] << 3*depth | curve_r(grid_coord[i]).
+ * grid_coord: (n,3) int32 (coord_is_i64=0) or int64 (=1); batch: (n) int64 or NULL;
+ * order_ids_host: k curve ids (host array); code: (k,n) int64. */
+int ptv3_sfc_encode(const void* grid_coord, int coord_is_i64, const int64_t* batch, int64_t n,
+                    int depth, const int* order_ids_host, int k, int64_t* code, void* stream);
+
+/* replaces torch.argsort + scatter_ of arange in Point.serialization
+ * (models/utils/structure.py:92-99) and SerializedPooling (point_transformer_v3m1_base.py:399-406):
+ * per row r: order[r] = stable argsort(code[r]); inverse[r][order[r][i]] = i.
+ * code: (k,n) non-negative int64 with all set bits below `end_bit`; order/inverse: (k,n) int64.
+ * workspace: ptv3_argsort_workspace_bytes(k,n) bytes. */
+size_t ptv3_argsort_workspace_bytes(int k, int64_t n);
+int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_bit, int64_t* order,
+                     int64_t* inverse, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- patch partition ----------------------------------------------------------------------
+ * replaces SerializedAttention.get_padding_and_inverse (point_transformer_v3m1_base.py:114-170).
+ * offset: (b) int64 cumulative scene ends (device); patch = K.  n_pad = sum_b pad_to_K(n_b).
+ * pad: (n_pad) int64, unpad: (n) int64, cu_seqlens: (n_pad/K + 1) int32. */
+int ptv3_pad_plan(const int64_t* offset, int b, int64_t n, int64_t n_pad, int patch, int64_t* pad,
+                  int64_t* unpad, int32_t* cu_seqlens, void* stream);
+
+/* composes the two gathers of SerializedAttention.forward (point_transformer_v3m1_base.py:184-185):
+ * win_order[p] = order[pad[p]] (n_pad), win_inverse[i] = unpad[inverse[i]] (n); int32 outputs. */
+int ptv3_window_maps(const int64_t* order, const int64_t* inverse, const int64_t* pad,
+                     const int64_t* unpad, int64_t n, int64_t n_pad, int32_t* win_order,
+                     int32_t* win_inverse, void* stream);
+
+/* ---- window attention ----------------------------------------------------------------------
+ * replaces the vanilla branch of SerializedAttention.forward (point_transformer_v3m1_base.py:188-216)
+ * = what flash_attn_varlen_qkvpacked_func computes on the reference's CUDA path (:208-214):
+ *   x = qkv[win_order]; per window of `patch` rows and head h:
+ *   out_w = softmax(scale * q k^T) v;  out[i] = concat_h(out_w)[win_inverse[i]].
+ * qkv: (n, 3*c) with channel layout [3][heads][c/heads]; out: (n, c).  c/heads must be 16, 32 or 64.
+ * rpe_bias (optional, may be NULL): (n_pad/patch, heads, patch, patch) fp32 added to the scores
+ * (RPE.forward, :29-48). */
+int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                         void* out, int64_t n, int64_t n_pad, int c, int heads, int patch, float scale,
+                         const float* rpe_bias, int dtype, void* stream);
+
+/* ---- sparse submanifold convolution + dense linear (one implicit-GEMM kernel) ---------------
+ * Hash of the active sites: replaces spconv's indice-pair generation behind
+ * spconv.SparseConvTensor / SubMConv3d(indice_key=...) (models/utils/structure.py:111-146,
+ * point_transformer_v3m1_base.py:277-284,499-506).
+ * indices: (n,4) int32 [batch,x,y,z] unique rows, 0 <= x,y,z < 65536, batch < 32768.
+ * table: `slots` int64 keys + `slots` int32 values, slots = power of two >= 2n
+ * (ptv3_subm_table_slots(n)); layout: keys first.  nbr: (n, kvol) int32, -1 = inactive;
+ * kernel offset index (a,b,c) -> a*k*k + b*k + c pairs with (x+a-k/2, y+b-k/2, z+c-k/2). */
+int64_t ptv3_subm_table_slots(int64_t n);
+int ptv3_subm_build_table(const int32_t* indices, int64_t n, void* table, int64_t slots, void* stream);
+int ptv3_subm_neighbors(const int32_t* indices, int64_t n, const void* table, int64_t slots, int ksize,
+                        int32_t* nbr, void* stream);
+
+/* y = epilogue( sum_{d<kvol} sum_{c<cin} w[o][d][c] * x[nbr[i][d]][c] ).
+ *   nbr == NULL, kvol == 1  ->  plain torch.nn.Linear: y = x @ w^T            (w: (cout, cin))
+ *   nbr != NULL             ->  spconv SubMConv3d, w: (cout, k,k,k, cin) = (cout, kvol, cin)
+ * epilogue, in this order, every pointer optional (NULL = skip):
+ *   + bias[o];  * bn_scale[o] + bn_shift[o]  (eval BatchNorm1d folded);  act;
+ *   y2 = y + res[res_index ? res_index[i] : i][o]   (written to `out2` if given, else into `out`);
+ * `out` always receives the pre-residual value when out2 != NULL.
+ * row_order (optional, (m) int32): output tile t processes rows row_order[64t..] (locality only).
+ * x: (rows_x, cin) dtype; out/out2/res: (m|rows, cout) dtype; w/bias/bn_*: see w_dtype (= dtype
+ * for w, fp32 for the vectors).  cin % 4 == 0. */
+int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int cin, int cout, int kvol,
+              const int32_t* nbr, const int32_t* row_order, const float* bias, const float* bn_scale,
+              const float* bn_shift, int act, const void* res, const int32_t* res_index, void* out2,
+              int dtype, void* stream);
+
+/* ---- normalisation / elementwise -------------------------------------------------------------
+ * torch.nn.LayerNorm over the last dim (Block.cpe[2], norm1, norm2; :277-304): y = LN(x)*g+b [+ res];
+ * optional second output y2 = LN2(y) * g2 + b2 (fuses `shortcut + cpe` with the following norm1). */
+int ptv3_layernorm(const void* x, const float* gamma, const float* beta, const void* res, void* y,
+                   const float* gamma2, const float* beta2, void* y2, int64_t m, int c, float eps,
+                   int dtype, void* stream);
+
+/* y = act(x * scale[c] + shift[c]) : eval BatchNorm1d + GELU of Embedding / SerializedPooling
+ * (:508-511, 439-442). In-place allowed. */
+int ptv3_affine_act(const void* x, const float* scale, const float* shift, int act, void* y, int64_t m,
+                    int c, int dtype, void* stream);
+
+/* dtype conversion helpers (fp32 <-> bf16 storage) */
+int ptv3_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t count, void* stream);
+
+/* ---- serialized pooling ("grid-pool scatter") ------------------------------------------------
+ * replaces torch.unique / torch.sort / cumsum / segment_csr in SerializedPooling.forward
+ * (point_transformer_v3m1_base.py:384-428).  Points are visited in serialized order 0, so clusters
+ * (equal code0 >> 3*pooling_depth) are contiguous runs of order0.
+ * step 1 (segments): cluster[i] (n) int64 = rank of the parent code; seg_start (n+1) int32 run starts
+ *         in order0 positions (first *n_out+1 entries valid); n_out written to device AND the
+ *         caller reads it back (the one host sync per pooling, as torch.unique has).
+ *         workspace: ptv3_pool_workspace_bytes(n). */
+size_t ptv3_pool_workspace_bytes(int64_t n);
+int ptv3_pool_segments(const int64_t* code0, const int64_t* order0, int64_t n, int shift_bits,
+                       int64_t* cluster, int32_t* seg_start, int32_t* n_out, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* step 2 (reduce): for pooled row j over members order0[seg_start[j] .. seg_start[j+1]):
+ *   feat_out[j]  = act(max_members(feat[.]) * bn_scale + bn_shift)        (n_out, c) dtype
+ *   coord_out[j] = mean_members(coord[.])                                  (n_out, 3) fp32
+ *   head = first member: grid_out[j] = grid_coord[head] >> pooling_depth (int64), batch_out[j] =
+ *   batch[head], code_out[r][j] = code[r][head] >> 3*pooling_depth for r < k. */
+int ptv3_pool_reduce(const void* feat, const float* coord, const int64_t* grid_coord,
+                     const int64_t* batch, const int64_t* code, int k, const int64_t* order0,
+                     const int32_t* seg_start, int64_t n, int64_t n_out, int c, int pooling_depth,
+                     const float* bn_scale, const float* bn_shift, int act, void* feat_out,
+                     float* coord_out, int64_t* grid_out, int64_t* batch_out, int64_t* code_out,
+                     int dtype, void* stream);
+
+/* ---- pointops (libs/pointops) ------------------------------------------------------------------
+ * Same argument meaning as the reference's extern "C" launchers
+ * (libs/pointops/src/knn_query/knn_query_cuda_kernel.h:9-17, grouping/grouping_cuda_kernel.h,
+ * interpolation/interpolation_cuda_kernel.h) plus the stream. */
+int ptv3_knn_query(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
+                   const int* new_offset, int b, int* idx, float* dist2, void* stream);
+int ptv3_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output,
+                          void* stream);
+int ptv3_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx,
+                           float* grad_input, void* stream);
+int ptv3_interpolation_forward(int n, int c, int k, const float* input, const int* idx,
+                               const float* weight, float* output, void* stream);
+int ptv3_interpolation_backward(int n, int c, int k, const float* grad_output, const int* idx,
+                                const float* weight, float* grad_input, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTV3_HIP_H */

@@ -1,0 +1,108 @@
+// Shared device helpers for the PTv3 hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PTV3_OK 0
+#define PTV3_ERR_ARG 1
+#define PTV3_ERR_LAUNCH 2
+#define PTV3_ERR_UNSUPPORTED 3
+
+#define PTV3_F32 0
+#define PTV3_BF16 1
+
+namespace ptv3 {
+
+void set_error(const char* fmt, ...);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// 4 contiguous elements of T as one register group
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef f32x4 type; };
+template <> struct Vec4<__bf16> { typedef s16x4 type; };
+
+template <typename T> __device__ __forceinline__ typename Vec4<T>::type zero4();
+template <> __device__ __forceinline__ f32x4 zero4<float>() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+template <> __device__ __forceinline__ s16x4 zero4<__bf16>() { return s16x4{0, 0, 0, 0}; }
+
+__device__ __forceinline__ short bf16_bits(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<short*>(&b);
+}
+__device__ __forceinline__ float bf16_to_f32(short s) {
+  unsigned u = ((unsigned)(unsigned short)s) << 16;
+  return __builtin_bit_cast(float, u);
+}
+
+template <typename T> __device__ __forceinline__ typename Vec4<T>::type pack4(float a, float b, float c, float d);
+template <> __device__ __forceinline__ f32x4 pack4<float>(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
+template <> __device__ __forceinline__ s16x4 pack4<__bf16>(float a, float b, float c, float d) {
+  return s16x4{bf16_bits(a), bf16_bits(b), bf16_bits(c), bf16_bits(d)};
+}
+template <typename T> __device__ __forceinline__ void unpack4(typename Vec4<T>::type v, float* o);
+template <> __device__ __forceinline__ void unpack4<float>(f32x4 v, float* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+template <> __device__ __forceinline__ void unpack4<__bf16>(s16x4 v, float* o) {
+  o[0] = bf16_to_f32(v[0]); o[1] = bf16_to_f32(v[1]); o[2] = bf16_to_f32(v[2]); o[3] = bf16_to_f32(v[3]);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__bf16>(__bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __bf16 from_f32<__bf16>(float v) { return (__bf16)v; }
+
+// One 16x16x16 matrix-core step, D = A*B + C, shared lane map for both dtypes:
+// lane l, i = l & 15, g = l >> 4 holds A[i][4g..4g+3], B[4g..4g+3][i]; acc reg r is D[4g+r][i].
+// f32: 4 x v_mfma_f32_16x16x4_f32 (exact fmaf chain); bf16: 1 x v_mfma_f32_16x16x16_bf16.
+template <typename T>
+__device__ __forceinline__ f32x4 mma16(typename Vec4<T>::type a, typename Vec4<T>::type b, f32x4 c);
+template <>
+__device__ __forceinline__ f32x4 mma16<float>(f32x4 a, f32x4 b, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+  return c;
+}
+template <>
+__device__ __forceinline__ f32x4 mma16<__bf16>(s16x4 a, s16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// Bijective XCD-aware remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+// XCD a contiguous run of logical ids (speed only, never correctness).
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned nx = 8;
+  if (nwg < nx * 2) return bid;
+  unsigned xcd = bid % nx, slot = bid / nx;
+  unsigned q = nwg / nx, r = nwg % nx;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}
+
+}  // namespace ptv3
+
+#define PTV3_LAUNCH_CHECK()                                              \
+  do {                                                                   \
+    hipError_t e__ = hipGetLastError();                                  \
+    if (e__ != hipSuccess) {                                             \
+      ptv3::set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e__)); \
+      return PTV3_ERR_LAUNCH;                                            \
+    }                                                                    \
+  } while (0)
+
+#define PTV3_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      ptv3::set_error(__VA_ARGS__);        \
+      return PTV3_ERR_ARG;                 \
+    }                                      \
+  } while (0)

@@ -1,0 +1,254 @@
+// Per-window QK^T / softmax / PV with the serialized-order gather and the inverse scatter fused in.
+// One workgroup = (window, head, block of queries); K and V of the window stream through LDS in
+// 64-key tiles (K row-major, V transposed), scores never leave registers (online softmax).
+// Matrix-core layout (mma16, common.h): S^T tile = K_tile(16 keys x 16 d) * Q^T  -> query on the
+// lane, keys in the 4 acc registers x 4 lane groups; that accumulator is directly the B operand
+// of O^T += V^T * P^T, so P never touches LDS.
+// Reference semantics: SerializedAttention.forward, point_transformer_v3m1_base.py:184-216.
+#include "common.h"
+#include "../../include/ptv3_hip.h"
+
+namespace ptv3 {
+
+constexpr int WA_THREADS = 256;
+constexpr int WA_WAVES = 4;
+constexpr int WA_KT = 64;  // keys per LDS tile
+
+template <typename T, int ND> struct WaCfg;
+template <typename T> struct WaCfg<T, 1> { static constexpr int QT = 4; };
+template <typename T> struct WaCfg<T, 2> { static constexpr int QT = 2; };
+template <typename T> struct WaCfg<T, 4> { static constexpr int QT = 1; };
+
+template <typename T, int ND>
+__global__ void __launch_bounds__(WA_THREADS)
+window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
+                   const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
+                   int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe) {
+  typedef typename Vec4<T>::type V4;
+  constexpr int D = 16 * ND;
+  constexpr int QT = WaCfg<T, ND>::QT;
+  constexpr int QB = WA_WAVES * QT * 16;  // queries per workgroup
+  constexpr int KS = D + 4;               // K tile row stride (elements)
+  constexpr int VS = WA_KT + 4;           // V^T tile row stride (elements)
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);                      // [WA_KT][KS]
+  T* sV = sK + WA_KT * KS;                                 // [D][VS]
+  int32_t* sOrd = reinterpret_cast<int32_t*>(sV + D * VS);  // [K]
+
+  const unsigned nwg = (unsigned)nwin * H * qsplit;
+  const unsigned logical = xcd_remap(blockIdx.x, nwg);
+  const int w = logical / (H * qsplit);
+  const int rem = logical % (H * qsplit);
+  const int h = rem / qsplit;
+  const int qs = rem % qsplit;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t wbase = (int64_t)w * K;
+  const int C3 = 3 * C;
+
+  for (int i = tid; i < K; i += WA_THREADS) sOrd[i] = win_order[wbase + i];
+  __syncthreads();
+
+  // ---- Q fragments (B operand of the score product), pre-scaled by scale*log2(e)
+  V4 qf[QT][ND];
+  int qidx[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qidx[t] = qs * QB + (wave * QT + t) * 16 + li;
+    const bool qv = qidx[t] < K;
+    const int row = qv ? sOrd[qidx[t]] : 0;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+      V4 raw = zero4<T>();
+      if (qv) raw = *reinterpret_cast<const V4*>(qkv + (int64_t)row * C3 + h * D + 16 * c + 4 * g);
+      float f[4];
+      unpack4<T>(raw, f);
+      qf[t][c] = pack4<T>(f[0] * scale_log2e, f[1] * scale_log2e, f[2] * scale_log2e, f[3] * scale_log2e);
+    }
+  }
+
+  f32x4 o[QT][ND];
+  float m[QT], l[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) o[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // ---- staging map: thread -> (key row, 4-element chunk); D/4 chunks per row, 64 rows
+  constexpr int CH = D / 4;                            // chunks per row
+  constexpr int LOADS = (WA_KT * CH) / WA_THREADS;     // = ND
+  V4 rk[LOADS], rv[LOADS];
+  const int ntiles = (K + WA_KT - 1) / WA_KT;
+
+  auto issue_loads = [&](int tile) {
+#pragma unroll
+    for (int u = 0; u < LOADS; ++u) {
+      int e = u * WA_THREADS + tid;
+      int kk = e / CH, ch = e % CH;
+      int key = tile * WA_KT + kk;
+      rk[u] = zero4<T>();
+      rv[u] = zero4<T>();
+      if (key < K) {
+        const T* base = qkv + (int64_t)sOrd[key] * C3 + h * D + 4 * ch;
+        rk[u] = *reinterpret_cast<const V4*>(base + C);
+        rv[u] = *reinterpret_cast<const V4*>(base + 2 * C);
+      }
+    }
+  };
+  auto write_lds = [&]() {
+#pragma unroll
+    for (int u = 0; u < LOADS; ++u) {
+      int e = u * WA_THREADS + tid;
+      int kk = e / CH, ch = e % CH;
+      *reinterpret_cast<V4*>(sK + kk * KS + 4 * ch) = rk[u];
+      const T* pv = reinterpret_cast<const T*>(&rv[u]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sV[(4 * ch + q) * VS + kk] = pv[q];
+    }
+  };
+
+  issue_loads(0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    write_lds();
+    __syncthreads();
+    if (tile + 1 < ntiles) issue_loads(tile + 1);
+
+    // fragments of this key tile shared by all query tiles of the wave
+    V4 kf[4][ND], vf[ND][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        kf[kt][c] = *reinterpret_cast<const V4*>(sK + (16 * kt + li) * KS + 16 * c + 4 * g);
+        vf[c][kt] = *reinterpret_cast<const V4*>(sV + (16 * c + li) * VS + 16 * kt + 4 * g);
+      }
+    const int key0 = tile * WA_KT;
+    const bool tail = key0 + WA_KT > K;
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      f32x4 s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < ND; ++c) acc = mma16<T>(kf[kt][c], qf[t][c], acc);
+        s[kt] = acc;
+      }
+      if (rpe != nullptr && qidx[t] < K) {
+        const float* rb = rpe + (((int64_t)w * H + h) * K + qidx[t]) * K;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = key0 + 16 * kt + 4 * g + r;
+            if (key < K) s[kt][r] += rb[key] * 1.44269504088896340736f;
+          }
+      }
+      if (tail) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + 16 * kt + 4 * g + r >= K) s[kt][r] = -INFINITY;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[t], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+      m[t] = mn;
+      float ps = 0.f;
+      V4 pf[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mn);
+        float p1 = __builtin_amdgcn_exp2f(s[kt][1] - mn);
+        float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mn);
+        float p3 = __builtin_amdgcn_exp2f(s[kt][3] - mn);
+        ps += (p0 + p1) + (p2 + p3);
+        pf[kt] = pack4<T>(p0, p1, p2, p3);
+      }
+      l[t] = l[t] * alpha + ps;
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        o[t][c] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) o[t][c] = mma16<T>(vf[c][kt], pf[kt], o[t][c]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, scatter back through the inverse map (dropping borrowed duplicates)
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    float lt = l[t];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = 1.0f / lt;
+    if (qidx[t] < K) {
+      const int row = sOrd[qidx[t]];
+      if (win_inverse[row] == (int32_t)(wbase + qidx[t])) {
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+          V4 v = pack4<T>(o[t][c][0] * inv, o[t][c][1] * inv, o[t][c][2] * inv, o[t][c][3] * inv);
+          *reinterpret_cast<V4*>(out + (int64_t)row * C + h * D + 16 * c + 4 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int ND>
+static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
+                              int K, int nwin, float scale, const float* rpe, hipStream_t s) {
+  constexpr int D = 16 * ND;
+  constexpr int QB = WA_WAVES * WaCfg<T, ND>::QT * 16;
+  const int qsplit = (K + QB - 1) / QB;
+  const size_t lds = (size_t)(WA_KT * (D + 4) + D * (WA_KT + 4)) * sizeof(T) + (size_t)K * 4;
+  const unsigned nwg = (unsigned)nwin * H * qsplit;
+  hipLaunchKernelGGL((window_attn_kernel<T, ND>), dim3(nwg), dim3(WA_THREADS), lds, s, (const T*)qkv, wo, wi,
+                     (T*)out, C, H, K, nwin, qsplit, scale * 1.44269504088896340736f, rpe);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+}  // namespace ptv3
+
+using namespace ptv3;
+
+extern "C" int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                    void* out, int64_t n, int64_t n_pad, int c, int heads, int patch,
+                                    float scale, const float* rpe_bias, int dtype, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(n_pad % patch == 0, "window_attn: n_pad=%lld is not a multiple of patch=%d", (long long)n_pad,
+               patch);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn: bad dtype %d", dtype);
+  const int d = c / heads;
+  if (n == 0) return PTV3_OK;
+  const int nwin = (int)(n_pad / patch);
+  hipStream_t s = (hipStream_t)stream;
+#define WA_CASE(T)                                                                                          \
+  switch (d) {                                                                                              \
+    case 16: return launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); \
+    case 32: return launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); \
+    case 64: return launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); \
+    default: break;                                                                                         \
+  }
+  if (dtype == PTV3_F32) { WA_CASE(float) } else { WA_CASE(__bf16) }
+#undef WA_CASE
+  set_error("window_attn: head_dim %d unsupported (16, 32, 64)", d);
+  return PTV3_ERR_UNSUPPORTED;
+}

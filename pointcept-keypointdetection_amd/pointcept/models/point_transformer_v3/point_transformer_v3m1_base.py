@@ -1,0 +1,538 @@
+"""Point Transformer V3 (mode 1) on MI355X: registry name "PT-v3m1".
+
+Drop-in counterpart of the reference's
+pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py: same class names
+(RPE, SerializedAttention, MLP, Block, SerializedPooling, SerializedUnpooling, Embedding,
+PointTransformerV3), same constructor keywords and defaults (:520-552), same module tree and
+state_dict keys (:595-697).  All arithmetic runs in libptv3_hip.so (include/ptv3_hip.h):
+serialization + radix argsort, pad plan, fused window attention, implicit-GEMM linear / sparse conv,
+LayerNorm, folded BatchNorm, segmented pooling.  `enable_flash` is accepted for config
+compatibility: both settings run the same fused window kernel; the flag only selects the reference's
+patch-size rule (:173-176) so results match the reference for either value.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ptv3_hip import ops
+from pointcept.models.builder import MODELS
+from pointcept.models.utils.misc import offset2bincount  # noqa: F401  (reference import surface)
+from pointcept.models.utils.structure import Point
+from pointcept.models.utils.sparse import SubMConv3d
+from pointcept.models.utils.hip_layers import (Linear, LayerNorm, BatchNorm1d, GELU, DropPath, _no_training)
+from pointcept.models.modules import PointModule, PointSequential
+
+
+class RPE(nn.Module):
+    """Relative position bias table (:29-48).  Off in the fork's configs (enable_rpe=False)."""
+
+    def __init__(self, patch_size, num_heads):
+        super().__init__()
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self.pos_bnd = int((4 * patch_size) ** (1 / 3) * 2)
+        self.rpe_num = 2 * self.pos_bnd + 1
+        self.rpe_table = nn.Parameter(torch.zeros(3 * self.rpe_num, num_heads))
+        nn.init.trunc_normal_(self.rpe_table, std=0.02)
+
+    def forward(self, coord):
+        # index plumbing (clamp / offset / gather of a (3*rpe_num, H) table); the bias is consumed by the
+        # HIP attention kernel.  TODO(next): fold the table lookup into the kernel.
+        idx = (coord.clamp(-self.pos_bnd, self.pos_bnd) + self.pos_bnd
+               + torch.arange(3, device=coord.device) * self.rpe_num)
+        out = self.rpe_table.float().index_select(0, idx.reshape(-1))
+        out = out.view(idx.shape + (-1,)).sum(3)
+        return out.permute(0, 3, 1, 2).contiguous()
+
+
+class SerializedAttention(PointModule):
+    def __init__(self, channels, num_heads, patch_size, qkv_bias=True, qk_scale=None, attn_drop=0.0,
+                 proj_drop=0.0, order_index=0, enable_rpe=False, enable_flash=True, upcast_attention=True,
+                 upcast_softmax=True):
+        super().__init__()
+        assert channels % num_heads == 0
+        self.channels = channels
+        self.num_heads = num_heads
+        self.scale = qk_scale or (channels // num_heads) ** -0.5
+        self.order_index = order_index
+        self.upcast_attention = upcast_attention
+        self.upcast_softmax = upcast_softmax
+        self.enable_rpe = enable_rpe
+        self.enable_flash = enable_flash
+        if enable_flash:
+            assert enable_rpe is False, "Set enable_rpe to False when enable Flash Attention"
+            assert upcast_attention is False, "Set upcast_attention to False when enable Flash Attention"
+            assert upcast_softmax is False, "Set upcast_softmax to False when enable Flash Attention"
+            self.patch_size = patch_size
+            self.attn_drop = attn_drop
+        else:
+            # the reference avoids masks: the patch shrinks to the smallest scene (:91-96)
+            self.patch_size_max = patch_size
+            self.patch_size = 0
+            self.attn_drop = nn.Dropout(attn_drop)
+        self.qkv = Linear(channels, channels * 3, bias=qkv_bias)
+        self.proj = Linear(channels, channels)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self.softmax = nn.Softmax(dim=-1)
+        self.rpe = RPE(patch_size, num_heads) if self.enable_rpe else None
+
+    @torch.no_grad()
+    def get_rel_pos(self, point, order):
+        K = self.patch_size
+        rel_pos_key = f"rel_pos_{self.order_index}"
+        if rel_pos_key not in point.keys():
+            grid_coord = point.grid_coord[order].reshape(-1, K, 3)
+            point[rel_pos_key] = grid_coord.unsqueeze(2) - grid_coord.unsqueeze(1)
+        return point[rel_pos_key]
+
+    @torch.no_grad()
+    def get_padding_and_inverse(self, point):
+        """pad / unpad / cu_seqlens, cached on the Point like the reference (:114-170)."""
+        pad_key, unpad_key, cu_seqlens_key = "pad", "unpad", "cu_seqlens_key"
+        if (pad_key not in point.keys() or unpad_key not in point.keys()
+                or cu_seqlens_key not in point.keys() or point.get("_pad_patch") != self.patch_size):
+            pad, unpad, cu = ops.pad_plan(point.offset.long().contiguous(), point.offset_host(), self.patch_size)
+            point[pad_key], point[unpad_key], point[cu_seqlens_key] = pad, unpad, cu
+            point["_pad_patch"] = self.patch_size
+            for k in [k for k in point.keys() if isinstance(k, str) and k.startswith("_win_maps_")]:
+                del point[k]
+        return point[pad_key], point[unpad_key], point[cu_seqlens_key]
+
+    @torch.no_grad()
+    def window_maps(self, point):
+        """order[pad] and unpad[inverse] (:184-185) as int32, cached per (Point, order_index)."""
+        key = f"_win_maps_{self.order_index}"
+        pad, unpad, _ = self.get_padding_and_inverse(point)
+        if key not in point.keys():
+            point[key] = ops.window_maps(point.serialized_order[self.order_index],
+                                         point.serialized_inverse[self.order_index], pad, unpad)
+        return point[key]
+
+    def resolve_patch_size(self, point):
+        if not self.enable_flash:
+            host = point.offset_host()
+            counts = [b - a for a, b in zip([0] + host[:-1], host)]
+            self.patch_size = min(min(counts), self.patch_size_max)
+        return self.patch_size
+
+    def attention_core(self, point, qkv):
+        """gather -> softmax(QK^T)V -> scatter (:188-216) in one kernel."""
+        K = self.resolve_patch_size(point)
+        wo, wi = self.window_maps(point)
+        bias = None
+        if self.enable_rpe:
+            bias = self.rpe(self.get_rel_pos(point, wo.long()))
+        return ops.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, rpe_bias=bias)
+
+    def forward(self, point):
+        _no_training(self)
+        qkv = self.qkv(point.feat)
+        feat = self.attention_core(point, qkv)
+        feat = self.proj(feat)
+        point.feat = feat
+        return point
+
+
+class MLP(nn.Module):
+    def __init__(self, in_channels, hidden_channels=None, out_channels=None, act_layer=GELU, drop=0.0):
+        super().__init__()
+        out_channels = out_channels or in_channels
+        hidden_channels = hidden_channels or in_channels
+        self.fc1 = Linear(in_channels, hidden_channels)
+        self.act = act_layer()
+        self.fc2 = Linear(hidden_channels, out_channels)
+        self.drop = nn.Dropout(drop)
+
+    def _act_id(self):
+        if isinstance(self.act, nn.GELU):
+            return ops.ACT_GELU
+        if isinstance(self.act, nn.ReLU):
+            return ops.ACT_RELU
+        return None
+
+    def forward(self, x, res=None):
+        act = self._act_id()
+        if act is None:
+            x = self.act(self.fc1(x))
+        else:
+            x = self.fc1(x, act=act)  # activation in the GEMM epilogue
+        return self.fc2(x, res=res)
+
+
+class Block(PointModule):
+    def __init__(self, channels, num_heads, patch_size=48, mlp_ratio=4.0, qkv_bias=True, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, drop_path=0.0, norm_layer=LayerNorm, act_layer=GELU,
+                 pre_norm=True, order_index=0, cpe_indice_key=None, enable_rpe=False, enable_flash=True,
+                 upcast_attention=True, upcast_softmax=True):
+        super().__init__()
+        self.channels = channels
+        self.pre_norm = pre_norm
+        self.cpe = PointSequential(
+            SubMConv3d(channels, channels, kernel_size=3, bias=True, indice_key=cpe_indice_key),
+            Linear(channels, channels),
+            norm_layer(channels),
+        )
+        self.norm1 = PointSequential(norm_layer(channels))
+        self.attn = SerializedAttention(
+            channels=channels, patch_size=patch_size, num_heads=num_heads, qkv_bias=qkv_bias,
+            qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop, order_index=order_index,
+            enable_rpe=enable_rpe, enable_flash=enable_flash, upcast_attention=upcast_attention,
+            upcast_softmax=upcast_softmax)
+        self.norm2 = PointSequential(norm_layer(channels))
+        self.mlp = PointSequential(MLP(in_channels=channels, hidden_channels=int(channels * mlp_ratio),
+                                       out_channels=channels, act_layer=act_layer, drop=proj_drop))
+        self.drop_path = PointSequential(DropPath(drop_path) if drop_path > 0.0 else nn.Identity())
+
+    def _fusable(self):
+        return (self.pre_norm and isinstance(self.cpe[2], LayerNorm) and isinstance(self.norm1[0], LayerNorm)
+                and isinstance(self.norm2[0], LayerNorm))
+
+    def forward(self, point: Point):
+        _no_training(self)
+        if not self._fusable():
+            return self._forward_generic(point)
+        # ---- fused eval path: 9 launches per block, residual adds and norms folded into epilogues
+        shortcut = point.feat
+        sp = self.cpe[0](point.sparse_conv_feat)            # xCPE conv (reads the sparse tensor's features)
+        x = self.cpe[1](sp.features)
+        g1, b1 = self.cpe[2].affine_f32()
+        g2, b2 = self.norm1[0].affine_f32()
+        feat, x = ops.layernorm(x, g1, b1, self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)
+        qkv = self.attn.qkv(x)
+        x = self.attn.attention_core(point, qkv)
+        feat = self.attn.proj(x, res=feat)                  # + shortcut
+        x = self.norm2[0](feat)
+        feat = self.mlp[0](x, res=feat)                     # fc1+GELU, fc2 + shortcut
+        point.feat = feat
+        point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(feat)
+        return point
+
+    def _forward_generic(self, point: Point):
+        """The reference's statement order (:318-338) on the unfused layer ops."""
+        shortcut = point.feat
+        point = self.cpe(point)
+        point.feat = _add(shortcut, point.feat)
+        shortcut = point.feat
+        if self.pre_norm:
+            point = self.norm1(point)
+        point = self.drop_path(self.attn(point))
+        point.feat = _add(shortcut, point.feat)
+        if not self.pre_norm:
+            point = self.norm1(point)
+        shortcut = point.feat
+        if self.pre_norm:
+            point = self.norm2(point)
+        point = self.drop_path(self.mlp(point))
+        point.feat = _add(shortcut, point.feat)
+        if not self.pre_norm:
+            point = self.norm2(point)
+        point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(point.feat)
+        return point
+
+
+def _add(a, b):
+    # residual add outside a fused epilogue: (m, c) elementwise, index-free -> torch plumbing
+    return a + b
+
+
+class SerializedPooling(PointModule):
+    def __init__(self, in_channels, out_channels, stride=2, norm_layer=None, act_layer=None, reduce="max",
+                 shuffle_orders=True, traceable=True):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        assert stride == 2 ** (math.ceil(stride) - 1).bit_length()  # 2, 4, 8
+        self.stride = stride
+        assert reduce in ["sum", "mean", "min", "max"]
+        if reduce != "max":
+            raise NotImplementedError("SerializedPooling on the HIP path implements reduce='max' (every PTv3 config)")
+        self.reduce = reduce
+        self.shuffle_orders = shuffle_orders
+        self.traceable = traceable
+        self.proj = Linear(in_channels, out_channels)
+        self.norm = PointSequential(norm_layer(out_channels)) if norm_layer is not None else None
+        self.act = PointSequential(act_layer()) if act_layer is not None else None
+
+    def forward(self, point: Point):
+        _no_training(self)
+        pooling_depth = (math.ceil(self.stride) - 1).bit_length()
+        if pooling_depth > point.serialized_depth:
+            pooling_depth = 0
+        assert {"serialized_code", "serialized_order", "serialized_inverse", "serialized_depth"}.issubset(
+            point.keys()), "Run point.serialization() point cloud before SerializedPooling"
+        code = point.serialized_code
+        order0 = point.serialized_order[0]
+        # clusters = runs of equal (code[0] >> 3*pooling_depth) along serialized order 0
+        cluster, seg_start, n_out = ops.pool_segments(code[0], order0, pooling_depth * 3)
+        k = code.shape[0]
+        if self.shuffle_orders:
+            # same CPU-RNG draw as the reference (:408-412); applied to the source rows so the pooled codes
+            # come out already permuted
+            perm = torch.randperm(k).tolist()
+        else:
+            perm = list(range(k))
+        code_src = code if perm == list(range(k)) else code[torch.tensor(perm, device=code.device)]
+        # folded BN + activation ride on the segmented max when they are the standard eval layers
+        bn = self.norm[0] if self.norm is not None and len(self.norm) == 1 and isinstance(self.norm[0], BatchNorm1d) else None
+        act_id = ops.ACT_NONE
+        fuse = (self.norm is None or bn is not None) and (self.act is None or isinstance(self.act[0], nn.GELU))
+        if fuse and self.act is not None:
+            act_id = ops.ACT_GELU
+        scale = shift = None
+        if fuse and bn is not None:
+            scale, shift = bn.folded()
+        proj = self.proj(point.feat)
+        feat, coord, grid_coord, batch, code_out = ops.pool_reduce(
+            proj, point.coord.float().contiguous() if "coord" in point.keys() else None,
+            point.grid_coord.long().contiguous(), point.batch.long().contiguous(), code_src, order0, seg_start,
+            n_out, pooling_depth, bn_scale=scale, bn_shift=shift, act=act_id if fuse else ops.ACT_NONE)
+        depth = point.serialized_depth - pooling_depth
+        nb = len(point.offset)
+        end_bit = max(1, depth * 3 + max(nb - 1, 0).bit_length())
+        order, inverse = ops.argsort_codes(code_out, end_bit)
+        point_dict = Point(
+            feat=feat, coord=coord, grid_coord=grid_coord, serialized_code=code_out, serialized_order=order,
+            serialized_inverse=inverse, serialized_depth=depth, batch=batch,
+            offset=torch.cumsum(torch.bincount(batch, minlength=nb), dim=0).long(),
+        )
+        if coord is None:
+            del point_dict["coord"]
+        if "_grid_max_host" in point.keys():
+            point_dict["_grid_max_host"] = [g >> pooling_depth for g in point["_grid_max_host"]]
+        if "condition" in point.keys():
+            point_dict["condition"] = point.condition
+        if "context" in point.keys():
+            point_dict["context"] = point.context
+        if self.traceable:
+            point_dict["pooling_inverse"] = cluster
+            point_dict["pooling_parent"] = point
+        point = point_dict
+        if not fuse:
+            if self.norm is not None:
+                point = self.norm(point)
+            if self.act is not None:
+                point = self.act(point)
+        point.sparsify()
+        return point
+
+
+class SerializedUnpooling(PointModule):
+    def __init__(self, in_channels, skip_channels, out_channels, norm_layer=None, act_layer=None,
+                 traceable=False):
+        super().__init__()
+        self.proj = PointSequential(Linear(in_channels, out_channels))
+        self.proj_skip = PointSequential(Linear(skip_channels, out_channels))
+        if norm_layer is not None:
+            self.proj.add(norm_layer(out_channels))
+            self.proj_skip.add(norm_layer(out_channels))
+        if act_layer is not None:
+            self.proj.add(act_layer())
+            self.proj_skip.add(act_layer())
+        self.traceable = traceable
+
+    @staticmethod
+    def _epilogue(seq):
+        """(bn_scale, bn_shift, act) when `seq` is Linear [+ eval BatchNorm1d] [+ GELU], else None."""
+        mods = list(seq._modules.values())
+        if not isinstance(mods[0], Linear):
+            return None
+        scale = shift = None
+        act = ops.ACT_NONE
+        rest = mods[1:]
+        if rest and isinstance(rest[0], BatchNorm1d):
+            scale, shift = rest[0].folded()
+            rest = rest[1:]
+        if rest and isinstance(rest[0], nn.GELU):
+            act = ops.ACT_GELU
+            rest = rest[1:]
+        if rest:
+            return None
+        return scale, shift, act
+
+    def forward(self, point):
+        _no_training(self)
+        assert "pooling_parent" in point.keys()
+        assert "pooling_inverse" in point.keys()
+        parent = point.pop("pooling_parent")
+        inverse = point.pop("pooling_inverse")
+        e1, e2 = self._epilogue(self.proj), self._epilogue(self.proj_skip)
+        if e1 is not None and e2 is not None:
+            # two GEMMs: up-branch, then skip-branch whose epilogue gathers the up-branch rows by cluster id
+            up = self.proj[0](point.feat, bn_scale=e1[0], bn_shift=e1[1], act=e1[2])
+            point.feat = up
+            skip, fused = self.proj_skip[0](parent.feat, bn_scale=e2[0], bn_shift=e2[1], act=e2[2], res=up,
+                                            res_index=inverse.int(), dual=True)
+            # The reference refreshes parent.sparse_conv_feat inside proj_skip (modules.py:97-103) but NOT
+            # after `parent.feat = parent.feat + point.feat[inverse]` (:478): the next Block's xCPE conv
+            # therefore sees the skip branch alone.  Reproduced on purpose.
+            parent.sparse_conv_feat = parent.sparse_conv_feat.replace_feature(skip)
+            parent.feat = fused
+        else:
+            point = self.proj(point)
+            parent = self.proj_skip(parent)
+            parent.feat = parent.feat + point.feat[inverse]
+        if self.traceable:
+            parent["unpooling_parent"] = point
+        return parent
+
+
+class Embedding(PointModule):
+    def __init__(self, in_channels, embed_channels, norm_layer=None, act_layer=None):
+        super().__init__()
+        self.in_channels = in_channels
+        self.embed_channels = embed_channels
+        self.stem = PointSequential(conv=SubMConv3d(in_channels, embed_channels, kernel_size=5, padding=1,
+                                                    bias=False, indice_key="stem"))
+        if norm_layer is not None:
+            self.stem.add(norm_layer(embed_channels), name="norm")
+        if act_layer is not None:
+            self.stem.add(act_layer(), name="act")
+
+    def forward(self, point: Point):
+        _no_training(self)
+        mods = self.stem._modules
+        bn, act = mods.get("norm"), mods.get("act")
+        if (bn is None or isinstance(bn, BatchNorm1d)) and (act is None or isinstance(act, nn.GELU)):
+            scale, shift = bn.folded() if bn is not None else (None, None)
+            sp = mods["conv"](point.sparse_conv_feat, bn_scale=scale, bn_shift=shift,
+                              act=ops.ACT_GELU if act is not None else ops.ACT_NONE)
+            point.sparse_conv_feat = sp
+            point.feat = sp.features
+            return point
+        return self.stem(point)
+
+
+@MODELS.register_module("PT-v3m1")
+class PointTransformerV3(PointModule):
+    def __init__(
+        self,
+        in_channels=6,
+        order=("z", "z-trans"),
+        stride=(2, 2, 2, 2),
+        enc_depths=(2, 2, 2, 6, 2),
+        enc_channels=(32, 64, 128, 256, 512),
+        enc_num_head=(2, 4, 8, 16, 32),
+        enc_patch_size=(48, 48, 48, 48, 48),
+        dec_depths=(2, 2, 2, 2),
+        dec_channels=(64, 64, 128, 256),
+        dec_num_head=(4, 4, 8, 16),
+        dec_patch_size=(48, 48, 48, 48),
+        mlp_ratio=4,
+        qkv_bias=True,
+        qk_scale=None,
+        attn_drop=0.0,
+        proj_drop=0.0,
+        drop_path=0.3,
+        pre_norm=True,
+        shuffle_orders=True,
+        enable_rpe=False,
+        enable_flash=True,
+        upcast_attention=False,
+        upcast_softmax=False,
+        enc_mode=False,
+        pdnorm_bn=False,
+        pdnorm_ln=False,
+        pdnorm_decouple=True,
+        pdnorm_adaptive=False,
+        pdnorm_affine=True,
+        pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D"),
+    ):
+        super().__init__()
+        self.num_stages = len(enc_depths)
+        self.order = [order] if isinstance(order, str) else order
+        self.enc_mode = enc_mode
+        self.shuffle_orders = shuffle_orders
+        # None: follow torch autocast (bf16) else fp32; or force torch.float32 / torch.bfloat16
+        self.compute_dtype = None
+
+        assert self.num_stages == len(stride) + 1
+        assert self.num_stages == len(enc_depths)
+        assert self.num_stages == len(enc_channels)
+        assert self.num_stages == len(enc_num_head)
+        assert self.num_stages == len(enc_patch_size)
+        assert self.enc_mode or self.num_stages == len(dec_depths) + 1
+        assert self.enc_mode or self.num_stages == len(dec_channels) + 1
+        assert self.enc_mode or self.num_stages == len(dec_num_head) + 1
+        assert self.enc_mode or self.num_stages == len(dec_patch_size) + 1
+
+        if pdnorm_bn or pdnorm_ln:
+            raise NotImplementedError("PDNorm (pdnorm_bn / pdnorm_ln) is off in every target config and is not "
+                                      "part of the MI355X path (SURVEY.md section 2a row 10)")
+        bn_layer = partial(BatchNorm1d, eps=1e-3, momentum=0.01)
+        ln_layer = LayerNorm
+        act_layer = GELU
+
+        self.embedding = Embedding(in_channels=in_channels, embed_channels=enc_channels[0], norm_layer=bn_layer,
+                                   act_layer=act_layer)
+
+        enc_drop_path = [x.item() for x in torch.linspace(0, drop_path, sum(enc_depths))]
+        self.enc = PointSequential()
+        for s in range(self.num_stages):
+            enc_drop_path_ = enc_drop_path[sum(enc_depths[:s]): sum(enc_depths[: s + 1])]
+            enc = PointSequential()
+            if s > 0:
+                enc.add(SerializedPooling(in_channels=enc_channels[s - 1], out_channels=enc_channels[s],
+                                          stride=stride[s - 1], norm_layer=bn_layer, act_layer=act_layer,
+                                          shuffle_orders=True), name="down")
+            for i in range(enc_depths[s]):
+                enc.add(Block(channels=enc_channels[s], num_heads=enc_num_head[s], patch_size=enc_patch_size[s],
+                              mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=proj_drop, drop_path=enc_drop_path_[i], norm_layer=ln_layer,
+                              act_layer=act_layer, pre_norm=pre_norm, order_index=i % len(self.order),
+                              cpe_indice_key=f"stage{s}", enable_rpe=enable_rpe, enable_flash=enable_flash,
+                              upcast_attention=upcast_attention, upcast_softmax=upcast_softmax),
+                        name=f"block{i}")
+            if len(enc) != 0:
+                self.enc.add(module=enc, name=f"enc{s}")
+
+        if not self.enc_mode:
+            dec_drop_path = [x.item() for x in torch.linspace(0, drop_path, sum(dec_depths))]
+            self.dec = PointSequential()
+            dec_channels = list(dec_channels) + [enc_channels[-1]]
+            for s in reversed(range(self.num_stages - 1)):
+                dec_drop_path_ = dec_drop_path[sum(dec_depths[:s]): sum(dec_depths[: s + 1])]
+                dec_drop_path_.reverse()
+                dec = PointSequential()
+                dec.add(SerializedUnpooling(in_channels=dec_channels[s + 1], skip_channels=enc_channels[s],
+                                            out_channels=dec_channels[s], norm_layer=bn_layer,
+                                            act_layer=act_layer), name="up")
+                for i in range(dec_depths[s]):
+                    dec.add(Block(channels=dec_channels[s], num_heads=dec_num_head[s],
+                                  patch_size=dec_patch_size[s], mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                  qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
+                                  drop_path=dec_drop_path_[i], norm_layer=ln_layer, act_layer=act_layer,
+                                  pre_norm=pre_norm, order_index=i % len(self.order),
+                                  cpe_indice_key=f"stage{s}", enable_rpe=enable_rpe, enable_flash=enable_flash,
+                                  upcast_attention=upcast_attention, upcast_softmax=upcast_softmax),
+                            name=f"block{i}")
+                self.dec.add(module=dec, name=f"dec{s}")
+
+    def resolve_dtype(self):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            if dt != torch.bfloat16:
+                raise NotImplementedError(f"autocast dtype {dt}: the MI355X path computes in bfloat16 or float32 "
+                                          "(set amp_dtype='bfloat16')")
+            return dt
+        return torch.float32
+
+    def forward(self, data_dict):
+        _no_training(self)
+        with torch.no_grad():
+            point = Point(data_dict)
+            dtype = self.resolve_dtype()
+            feat = point.feat
+            if feat.dtype not in (torch.float32, torch.bfloat16):
+                feat = feat.float()
+            point.feat = ops.cast(feat.contiguous(), dtype)
+            point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
+            point.sparsify()
+            point = self.embedding(point)
+            point = self.enc(point)
+            if not self.enc_mode:
+                point = self.dec(point)
+        return point

@@ -1,0 +1,75 @@
+"""Loads lib/libptv3_hip.so and declares the C ABI of include/ptv3_hip.h for ctypes."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+PTV3_F32, PTV3_BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+ORDER_IDS = {"z": 0, "z-trans": 1, "hilbert": 2, "hilbert-trans": 3}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def library_path():
+    return os.environ.get("PTV3_HIP_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libptv3_hip.so"))
+
+
+P = c_void_p
+# name -> (restype, argtypes); must list every symbol include/ptv3_hip.h declares
+SIGNATURES = {
+    "ptv3_last_error": (c_char_p, []),
+    "ptv3_version": (c_int, []),
+    "ptv3_sfc_encode": (c_int, [P, c_int, P, c_int64, c_int, P, c_int, P, P]),
+    "ptv3_argsort_workspace_bytes": (c_size_t, [c_int, c_int64]),
+    "ptv3_argsort_i64": (c_int, [P, c_int, c_int64, c_int, P, P, P, c_size_t, P]),
+    "ptv3_pad_plan": (c_int, [P, c_int, c_int64, c_int64, c_int, P, P, P, P]),
+    "ptv3_window_maps": (c_int, [P, P, P, P, c_int64, c_int64, P, P, P]),
+    "ptv3_window_attn_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, P, c_int, P]),
+    "ptv3_subm_table_slots": (c_int64, [c_int64]),
+    "ptv3_subm_build_table": (c_int, [P, c_int64, P, c_int64, P]),
+    "ptv3_subm_neighbors": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),
+    "ptv3_gemm": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, c_int, P]),
+    "ptv3_layernorm": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
+    "ptv3_affine_act": (c_int, [P, P, P, c_int, P, c_int64, c_int, c_int, P]),
+    "ptv3_cast": (c_int, [P, c_int, P, c_int, c_int64, P]),
+    "ptv3_pool_workspace_bytes": (c_size_t, [c_int64]),
+    "ptv3_pool_segments": (c_int, [P, P, c_int64, c_int, P, P, P, P, c_size_t, P]),
+    "ptv3_pool_reduce": (c_int, [P, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, P, P, c_int, P, P, P,
+                                 P, P, c_int, P]),
+    "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),
+    "ptv3_grouping_forward": (c_int, [c_int, c_int, c_int, P, P, P, P]),
+    "ptv3_grouping_backward": (c_int, [c_int, c_int, c_int, P, P, P, P]),
+    "ptv3_interpolation_forward": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
+    "ptv3_interpolation_backward": (c_int, [c_int, c_int, c_int, P, P, P, P, P]),
+}
+
+
+class _Lib:
+    """Lazy handle: importing the package on a box without the .so works, using an op does not."""
+
+    def __init__(self):
+        self._dll = None
+
+    def load(self):
+        if self._dll is None:
+            path = library_path()
+            if not os.path.exists(path):
+                raise ImportError(
+                    f"libptv3_hip.so not found at {path}: build it with `make -C pointcept-keypointdetection_amd` "
+                    "(or __graft_entry__.build()); there is no CPU fallback for the PTv3 HIP path")
+            dll = ctypes.CDLL(path)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(dll, name)
+                fn.restype, fn.argtypes = res, args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        return getattr(self.load(), name)
+
+    def check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed (code {rc}): {self.load().ptv3_last_error().decode()}")
+
+
+lib = _Lib()

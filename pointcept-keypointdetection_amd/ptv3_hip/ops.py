@@ -1,0 +1,271 @@
+"""Tensor-level wrappers over the C ABI (include/ptv3_hip.h).
+
+torch supplies device memory and the current HIP stream; all arithmetic happens in libptv3_hip.so.
+Every wrapper validates device / dtype / contiguity on the host before a pointer reaches a kernel.
+"""
+import ctypes
+
+import torch
+
+from .lib import lib, PTV3_F32, PTV3_BF16, ACT_NONE, ACT_GELU, ACT_RELU, ORDER_IDS  # noqa: F401
+
+_DT = {torch.float32: PTV3_F32, torch.bfloat16: PTV3_BF16}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=None, dim=None):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a GPU tensor (the PTv3 HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+    if dtype is not None and t.dtype not in (dtype if isinstance(dtype, tuple) else (dtype,)):
+        raise TypeError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if dim is not None and t.dim() != dim:
+        raise RuntimeError(f"{name}: {t.dim()}-d tensor, expected {dim}-d")
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported feature dtype {t.dtype} (float32 or bfloat16)")
+
+
+# ---------------------------------------------------------------------------------------------
+# serialization
+# ---------------------------------------------------------------------------------------------
+def sfc_encode(grid_coord, batch, depth, orders):
+    """code (k, n) int64; replaces encode() of utils/serialization/default.py:9-24 for k orders."""
+    _chk(grid_coord, "grid_coord", (torch.int32, torch.int64), 2)
+    _chk(batch, "batch", torch.int64, 1)
+    n = grid_coord.shape[0]
+    ids = (ctypes.c_int * len(orders))(*[ORDER_IDS[o] for o in orders])
+    code = torch.empty((len(orders), n), dtype=torch.int64, device=grid_coord.device)
+    lib.check(lib.ptv3_sfc_encode(_p(grid_coord), int(grid_coord.dtype == torch.int64), _p(batch), n, int(depth),
+                                  ids, len(orders), _p(code), _stream()), "ptv3_sfc_encode")
+    return code
+
+
+def argsort_codes(code, end_bit):
+    """(order, inverse), both (k, n) int64: stable argsort of every row + its inverse permutation."""
+    _chk(code, "code", torch.int64, 2)
+    k, n = code.shape
+    order = torch.empty_like(code)
+    inverse = torch.empty_like(code)
+    ws_bytes = lib.ptv3_argsort_workspace_bytes(k, n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=code.device)
+    lib.check(lib.ptv3_argsort_i64(_p(code), k, n, int(end_bit), _p(order), _p(inverse), _p(ws), ws_bytes,
+                                   _stream()), "ptv3_argsort_i64")
+    return order, inverse
+
+
+def pad_plan(offset, offset_host, patch):
+    """pad, unpad, cu_seqlens of SerializedAttention.get_padding_and_inverse (v3m1_base.py:114-170)."""
+    _chk(offset, "offset", torch.int64, 1)
+    prev, n_pad = 0, 0
+    for o in offset_host:
+        cnt = o - prev
+        n_pad += (cnt + patch - 1) // patch * patch if cnt > patch else cnt
+        prev = o
+    n = int(offset_host[-1])
+    nwin = sum((((o - p) + patch - 1) // patch) for p, o in zip([0] + list(offset_host[:-1]), offset_host))
+    pad = torch.empty(n_pad, dtype=torch.int64, device=offset.device)
+    unpad = torch.empty(n, dtype=torch.int64, device=offset.device)
+    cu = torch.empty(nwin + 1, dtype=torch.int32, device=offset.device)
+    lib.check(lib.ptv3_pad_plan(_p(offset), len(offset_host), n, n_pad, int(patch), _p(pad), _p(unpad), _p(cu),
+                                _stream()), "ptv3_pad_plan")
+    return pad, unpad, cu
+
+
+def window_maps(order, inverse, pad, unpad):
+    for t, nm in ((order, "order"), (inverse, "inverse"), (pad, "pad"), (unpad, "unpad")):
+        _chk(t, nm, torch.int64, 1)
+    n, n_pad = order.shape[0], pad.shape[0]
+    wo = torch.empty(n_pad, dtype=torch.int32, device=order.device)
+    wi = torch.empty(n, dtype=torch.int32, device=order.device)
+    lib.check(lib.ptv3_window_maps(_p(order), _p(inverse), _p(pad), _p(unpad), n, n_pad, _p(wo), _p(wi), _stream()),
+              "ptv3_window_maps")
+    return wo, wi
+
+
+def window_attention(qkv, win_order, win_inverse, heads, patch, scale, rpe_bias=None):
+    """softmax(scale q k^T) v per window with gather/scatter fused (v3m1_base.py:188-216)."""
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    _chk(rpe_bias, "rpe_bias", torch.float32)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    if win_inverse.shape[0] != n or c * 3 != c3:
+        raise RuntimeError("window_attention: shape mismatch")
+    n_pad = win_order.shape[0]
+    if rpe_bias is not None and rpe_bias.numel() != (n_pad // patch) * heads * patch * patch:
+        raise RuntimeError("window_attention: rpe_bias must be (n_pad/patch, heads, patch, patch)")
+    out = torch.empty((n, c), dtype=qkv.dtype, device=qkv.device)
+    lib.check(lib.ptv3_window_attn_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(out), n, n_pad, c, int(heads),
+                                       int(patch), float(scale), _p(rpe_bias), _dt(qkv), _stream()),
+              "ptv3_window_attn_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# sparse conv support + the implicit GEMM
+# ---------------------------------------------------------------------------------------------
+def subm_neighbors(indices, ksize, table=None):
+    """(nbr (n, ksize^3) int32, table) for unique (n,4) int32 [b,x,y,z] sites."""
+    _chk(indices, "indices", torch.int32, 2)
+    n = indices.shape[0]
+    if table is None:
+        slots = lib.ptv3_subm_table_slots(n)
+        table = torch.empty(slots * 12, dtype=torch.uint8, device=indices.device)
+        lib.check(lib.ptv3_subm_build_table(_p(indices), n, _p(table), slots, _stream()), "ptv3_subm_build_table")
+    slots = table.numel() // 12
+    nbr = torch.empty((n, ksize ** 3), dtype=torch.int32, device=indices.device)
+    lib.check(lib.ptv3_subm_neighbors(_p(indices), n, _p(table), slots, int(ksize), _p(nbr), _stream()),
+              "ptv3_subm_neighbors")
+    return nbr, table
+
+
+def gemm(x, w, bias=None, nbr=None, kvol=1, row_order=None, bn_scale=None, bn_shift=None, act=ACT_NONE,
+         res=None, res_index=None, dual=False, m=None):
+    """out = epi(sum_d sum_c w[o][d][c] x[nbr[i][d]][c]); see ptv3_gemm in include/ptv3_hip.h.
+
+    Returns out, or (out_pre_residual, out_with_residual) when dual=True."""
+    _chk(x, "x", (torch.float32, torch.bfloat16), 2)
+    _chk(w, "w", x.dtype)
+    for t, nm in ((bias, "bias"), (bn_scale, "bn_scale"), (bn_shift, "bn_shift")):
+        _chk(t, nm, torch.float32, 1)
+    _chk(nbr, "nbr", torch.int32, 2)
+    _chk(row_order, "row_order", torch.int32, 1)
+    _chk(res, "res", x.dtype, 2)
+    _chk(res_index, "res_index", torch.int32, 1)
+    cin = x.shape[1]
+    cout = w.shape[0]
+    if w.numel() != cout * kvol * cin:
+        raise RuntimeError(f"gemm: weight has {w.numel()} elements, expected {cout}x{kvol}x{cin}")
+    if m is None:
+        m = nbr.shape[0] if nbr is not None else x.shape[0]
+    if nbr is not None and (nbr.shape[0] != m or nbr.shape[1] != kvol):
+        raise RuntimeError("gemm: neighbour table shape mismatch")
+    for t in (bias, bn_scale, bn_shift):
+        if t is not None and t.numel() != cout:
+            raise RuntimeError("gemm: epilogue vector length != cout")
+    if res is not None:
+        if res.shape[1] != cout or (res_index is None and res.shape[0] != m):
+            raise RuntimeError("gemm: residual shape mismatch")
+        if res_index is not None and res_index.shape[0] != m:
+            raise RuntimeError("gemm: res_index length != m")
+    if row_order is not None and row_order.shape[0] != m:
+        raise RuntimeError("gemm: row_order length != m")
+    out = torch.empty((m, cout), dtype=x.dtype, device=x.device)
+    out2 = torch.empty_like(out) if dual else None
+    lib.check(lib.ptv3_gemm(_p(x), _p(w), _p(out), m, cin, cout, int(kvol), _p(nbr), _p(row_order), _p(bias),
+                            _p(bn_scale), _p(bn_shift), int(act), _p(res), _p(res_index), _p(out2), _dt(x),
+                            _stream()), "ptv3_gemm")
+    return (out, out2) if dual else out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, res=None, gamma2=None, beta2=None):
+    """y = LN(x)*g+b (+res); with gamma2/beta2 also returns y2 = LN(y)*g2+b2."""
+    _chk(x, "x", (torch.float32, torch.bfloat16), 2)
+    _chk(gamma, "gamma", torch.float32, 1)
+    _chk(beta, "beta", torch.float32, 1)
+    _chk(res, "res", x.dtype, 2)
+    _chk(gamma2, "gamma2", torch.float32, 1)
+    _chk(beta2, "beta2", torch.float32, 1)
+    m, c = x.shape
+    if gamma.numel() != c or beta.numel() != c or (res is not None and res.shape != x.shape):
+        raise RuntimeError("layernorm: shape mismatch")
+    y = torch.empty_like(x)
+    y2 = torch.empty_like(x) if gamma2 is not None else None
+    lib.check(lib.ptv3_layernorm(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(gamma2), _p(beta2), _p(y2), m, c,
+                                 float(eps), _dt(x), _stream()), "ptv3_layernorm")
+    return (y, y2) if gamma2 is not None else y
+
+
+def affine_act(x, scale, shift, act):
+    _chk(x, "x", (torch.float32, torch.bfloat16), 2)
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    m, c = x.shape
+    y = torch.empty_like(x)
+    lib.check(lib.ptv3_affine_act(_p(x), _p(scale), _p(shift), int(act), _p(y), m, c, _dt(x), _stream()),
+              "ptv3_affine_act")
+    return y
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    _chk(x, "x", (torch.float32, torch.bfloat16))
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    lib.check(lib.ptv3_cast(_p(x), _dt(x), _p(y), _DT[dtype], x.numel(), _stream()), "ptv3_cast")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------
+# serialized pooling
+# ---------------------------------------------------------------------------------------------
+def pool_segments(code0, order0, shift_bits):
+    """cluster (n) int64, seg_start (n_out+1) int32, n_out (python int; ONE host sync, as torch.unique)."""
+    _chk(code0, "code0", torch.int64, 1)
+    _chk(order0, "order0", torch.int64, 1)
+    n = code0.shape[0]
+    cluster = torch.empty(n, dtype=torch.int64, device=code0.device)
+    seg_start = torch.empty(n + 1, dtype=torch.int32, device=code0.device)
+    n_out = torch.empty(1, dtype=torch.int32, device=code0.device)
+    ws_bytes = lib.ptv3_pool_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=code0.device)
+    lib.check(lib.ptv3_pool_segments(_p(code0), _p(order0), n, int(shift_bits), _p(cluster), _p(seg_start),
+                                     _p(n_out), _p(ws), ws_bytes, _stream()), "ptv3_pool_segments")
+    cnt = int(n_out.item())
+    return cluster, seg_start[:cnt + 1], cnt
+
+
+def pool_reduce(feat, coord, grid_coord, batch, code, order0, seg_start, n_out, pooling_depth, bn_scale=None,
+                bn_shift=None, act=ACT_NONE):
+    _chk(feat, "feat", (torch.float32, torch.bfloat16), 2)
+    _chk(coord, "coord", torch.float32, 2)
+    _chk(grid_coord, "grid_coord", torch.int64, 2)
+    _chk(batch, "batch", torch.int64, 1)
+    _chk(code, "code", torch.int64, 2)
+    _chk(order0, "order0", torch.int64, 1)
+    _chk(seg_start, "seg_start", torch.int32, 1)
+    n, c = feat.shape
+    k = code.shape[0]
+    dev = feat.device
+    feat_out = torch.empty((n_out, c), dtype=feat.dtype, device=dev)
+    coord_out = torch.empty((n_out, 3), dtype=torch.float32, device=dev) if coord is not None else None
+    grid_out = torch.empty((n_out, 3), dtype=torch.int64, device=dev)
+    batch_out = torch.empty(n_out, dtype=torch.int64, device=dev)
+    code_out = torch.empty((k, n_out), dtype=torch.int64, device=dev)
+    lib.check(lib.ptv3_pool_reduce(_p(feat), _p(coord), _p(grid_coord), _p(batch), _p(code), k, _p(order0),
+                                   _p(seg_start), n, n_out, c, int(pooling_depth), _p(bn_scale), _p(bn_shift),
+                                   int(act), _p(feat_out), _p(coord_out), _p(grid_out), _p(batch_out), _p(code_out),
+                                   _dt(feat), _stream()), "ptv3_pool_reduce")
+    return feat_out, coord_out, grid_out, batch_out, code_out
+
+
+# ---------------------------------------------------------------------------------------------
+# pointops
+# ---------------------------------------------------------------------------------------------
+def knn_query(nsample, xyz, offset, new_xyz, new_offset):
+    _chk(xyz, "xyz", torch.float32, 2)
+    _chk(new_xyz, "new_xyz", torch.float32, 2)
+    _chk(offset, "offset", torch.int32, 1)
+    _chk(new_offset, "new_offset", torch.int32, 1)
+    m = new_xyz.shape[0]
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+    lib.check(lib.ptv3_knn_query(m, int(nsample), _p(xyz), _p(new_xyz), _p(offset), _p(new_offset),
+                                 offset.shape[0], _p(idx), _p(dist2), _stream()), "ptv3_knn_query")
+    return idx, dist2

@@ -1,0 +1,412 @@
+"""GPU parity: every HIP entry point (through the C ABI) against the oracle / the golden vectors.
+
+Bit-exact for integer outputs (codes, order, inverse, pad plan, cluster ids, neighbour tables, knn idx);
+fp32 feature outputs within 1e-4 of the oracle (tolerance of BASELINE.json north_star); bf16 mode is
+checked against the fp32 oracle with a bf16-sized tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from make_golden_cfg import ORDERS, TINY_CFG, FORK_CFG  # noqa: E402
+
+FP32_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch.device("cuda:0")
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ------------------------------------------------------------------------------------------------
+# serialization
+# ------------------------------------------------------------------------------------------------
+def test_sfc_encode_golden(dev, golden_dir):
+    from ptv3_hip import ops
+    g = _g(golden_dir, "sfc.npz")
+    for depth in (3, 5, 7, 10, 16):
+        for B in (1, 2, 8):
+            t = f"d{depth}_b{B}"
+            for dt in (torch.int64, torch.int32):
+                gc = torch.from_numpy(g[t + "_grid_coord"]).to(dev).to(dt)
+                batch = torch.from_numpy(g[t + "_batch"]).to(dev)
+                code = ops.sfc_encode(gc, batch, depth, ORDERS)
+                assert np.array_equal(code.cpu().numpy(), g[t + "_code"]), (t, dt)
+                end_bit = depth * 3 + max(B - 1, 0).bit_length()
+                order, inverse = ops.argsort_codes(code, max(1, end_bit))
+                assert np.array_equal(order.cpu().numpy(), g[t + "_order"]), t
+                assert np.array_equal(inverse.cpu().numpy(), g[t + "_inverse"]), t
+
+
+def test_sfc_encode_large_vs_oracle(dev):
+    from ptv3_hip import ops
+    from oracle import sfc
+    import ptv3_scenes as S
+    data = S.make_batch([60000, 41000], in_channels=4, extent=512, seed=5)
+    gc, off = data["grid_coord"], data["offset"]
+    batch = torch.repeat_interleave(torch.arange(2), torch.diff(off, prepend=torch.zeros(1, dtype=torch.long)))
+    depth = sfc.serialized_depth(gc.numpy())
+    code = ops.sfc_encode(gc.to(dev), batch.to(dev), depth, ORDERS)
+    ref_code, ref_order, ref_inv, _ = sfc.serialization(gc.numpy(), batch.numpy(), ORDERS, depth)
+    assert np.array_equal(code.cpu().numpy(), ref_code)
+    order, inverse = ops.argsort_codes(code, depth * 3 + 1)
+    assert np.array_equal(order.cpu().numpy(), ref_order)
+    assert np.array_equal(inverse.cpu().numpy(), ref_inv)
+
+
+@pytest.mark.parametrize("n,k,bits", [(1, 1, 8), (63, 2, 9), (2048, 1, 16), (2049, 3, 24), (100000, 4, 31),
+                                        (1 << 20, 2, 49), (300007, 1, 63)])
+def test_argsort_properties(dev, n, k, bits):
+    """size-independent properties at and beyond BASELINE sizes: sortedness, stability, inverse."""
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(n + bits)
+    hi = torch.randint(0, 1 << min(bits, 31), (k, n), generator=g, dtype=torch.int64)
+    lo = torch.randint(0, 1 << 31, (k, n), generator=g, dtype=torch.int64)
+    code = ((hi << 31) | lo) & ((1 << bits) - 1)
+    if n > 10:
+        code[:, n // 2] = code[:, n // 3]  # force ties: stable order must keep the lower index first
+    code = code.to(dev)
+    order, inverse = ops.argsort_codes(code, bits)
+    ref = torch.argsort(code.cpu(), dim=1, stable=True)
+    assert torch.equal(order.cpu(), ref)
+    ar = torch.arange(n).repeat(k, 1)
+    assert torch.equal(torch.gather(inverse.cpu(), 1, ref), ar)
+
+
+def test_pad_plan_golden(dev, golden_dir):
+    from ptv3_hip import ops
+    g = _g(golden_dir, "padplan.npz")
+    for i in range(int(g["n_cases"])):
+        off = g[f"c{i}_offset"]
+        K = int(g[f"c{i}_K"])
+        pad, unpad, cu = ops.pad_plan(torch.from_numpy(off).to(dev), off.tolist(), K)
+        assert np.array_equal(pad.cpu().numpy(), g[f"c{i}_pad"]), i
+        assert np.array_equal(unpad.cpu().numpy(), g[f"c{i}_unpad"]), i
+        assert np.array_equal(cu.cpu().numpy(), g[f"c{i}_cu"]), i
+
+
+# ------------------------------------------------------------------------------------------------
+# window attention
+# ------------------------------------------------------------------------------------------------
+def _attn_case(g, i, dev):
+    from oracle import sfc
+    t = f"a{i}_"
+    C, H, pmax, oi, rpe, K = [int(v) for v in g[t + "cfg"]]
+    off, gc = g[t + "offset"], g[t + "grid_coord"]
+    batch = np.repeat(np.arange(len(off)), np.diff(off, prepend=0))
+    code, order, inverse, _ = sfc.serialization(gc, batch, ORDERS)
+    pad, unpad, _ = sfc.pad_plan(off, K)
+    w = {k[len(t) + 2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(t + "w_")}
+    return dict(C=C, H=H, K=K, oi=oi, rpe=rpe, pmax=pmax, off=off, gc=gc, order=order[oi], inverse=inverse[oi],
+                pad=pad, unpad=unpad, w=w, qkv=g[t + "qkv"], feat=g[t + "feat"], out=g[t + "out"])
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+def test_window_attention_golden_fp32(dev, golden_dir, case):
+    from ptv3_hip import ops
+    from oracle import ptv3 as O
+    c = _attn_case(_g(golden_dir, "attention.npz"), case, dev)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    wo, wi = ops.window_maps(to(c["order"]), to(c["inverse"]), to(c["pad"]), to(c["unpad"]))
+    assert np.array_equal(wo.cpu().numpy(), c["order"][c["pad"]])
+    assert np.array_equal(wi.cpu().numpy(), c["unpad"][c["inverse"]])
+    out = ops.window_attention(to(c["qkv"]), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
+    core = O.window_attention_core(torch.from_numpy(c["qkv"]), torch.from_numpy(c["order"]),
+                                   torch.from_numpy(c["inverse"]), torch.from_numpy(c["pad"]),
+                                   torch.from_numpy(c["unpad"]), c["H"], c["K"])
+    assert (out.cpu() - core).abs().max().item() < FP32_TOL
+    # through the projection GEMM: the reference module's output
+    proj = ops.gemm(out, to(c["w"]["proj.weight"].numpy()), bias=to(c["w"]["proj.bias"].numpy()))
+    assert (proj.cpu() - torch.from_numpy(c["out"])).abs().max().item() < FP32_TOL
+
+
+def test_window_attention_bf16(dev, golden_dir):
+    from ptv3_hip import ops
+    c = _attn_case(_g(golden_dir, "attention.npz"), 2, dev)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    wo, wi = ops.window_maps(to(c["order"]), to(c["inverse"]), to(c["pad"]), to(c["unpad"]))
+    qkv = to(c["qkv"])
+    ref = ops.window_attention(qkv, wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
+    out = ops.window_attention(qkv.bfloat16(), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
+    assert out.dtype == torch.bfloat16
+    err = (out.float() - ref).abs().max().item()
+    assert err < 3e-2, err
+
+
+def test_window_attention_rpe(dev, golden_dir):
+    from ptv3_hip import ops
+    from oracle import ptv3 as O
+    c = _attn_case(_g(golden_dir, "attention.npz"), 5, dev)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    wo, wi = ops.window_maps(to(c["order"]), to(c["inverse"]), to(c["pad"]), to(c["unpad"]))
+    o = torch.from_numpy(c["order"])[torch.from_numpy(c["pad"])]
+    bias = O.rpe_bias(c["w"]["rpe.rpe_table"], torch.from_numpy(c["gc"])[o], c["K"], c["pmax"], c["H"]).contiguous()
+    out = ops.window_attention(to(c["qkv"]), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5,
+                               rpe_bias=bias.to(dev))
+    proj = ops.gemm(out, to(c["w"]["proj.weight"].numpy()), bias=to(c["w"]["proj.bias"].numpy()))
+    assert (proj.cpu() - torch.from_numpy(c["out"])).abs().max().item() < FP32_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# implicit GEMM: linear and sparse conv
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,cin,cout", [(1, 4, 4), (67, 32, 96), (1000, 64, 19), (513, 128, 512), (4099, 512, 24),
+                                         (300, 36, 64)])
+def test_linear_fp32(dev, m, cin, cout):
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(m + cin)
+    x = torch.randn(m, cin, generator=g)
+    w = torch.randn(cout, cin, generator=g) / cin ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = torch.nn.functional.linear(x, w, b)
+    out = ops.gemm(x.to(dev), w.to(dev), bias=b.to(dev))
+    assert (out.cpu() - ref).abs().max().item() < FP32_TOL
+    # full epilogue: folded BN, GELU, indexed residual, dual output
+    s, t = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g)
+    res = torch.randn(17, cout, generator=g)
+    ridx = torch.randint(0, 17, (m,), generator=g, dtype=torch.int32)
+    pre = torch.nn.functional.gelu(ref * s + t)
+    o1, o2 = ops.gemm(x.to(dev), w.to(dev), bias=b.to(dev), bn_scale=s.to(dev), bn_shift=t.to(dev),
+                      act=ops.ACT_GELU, res=res.to(dev), res_index=ridx.to(dev), dual=True)
+    assert (o1.cpu() - pre).abs().max().item() < FP32_TOL
+    assert (o2.cpu() - (pre + res[ridx.long()])).abs().max().item() < FP32_TOL
+
+
+def test_linear_bf16(dev):
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(777, 128, generator=g)
+    w = torch.randn(96, 128, generator=g) / 128 ** 0.5
+    b = torch.randn(96, generator=g)
+    ref = torch.nn.functional.linear(x.bfloat16().float(), w.bfloat16().float(), b)
+    out = ops.gemm(x.to(dev).bfloat16(), w.to(dev).bfloat16(), bias=b.to(dev))
+    assert (out.float().cpu() - ref).abs().max().item() < 5e-2
+
+
+@pytest.mark.parametrize("n,cin,cout,k", [(3000, 4, 32, 5), (2500, 32, 32, 3), (1200, 64, 64, 3), (700, 8, 16, 3)])
+def test_subm_conv_vs_oracle(dev, n, cin, cout, k):
+    from ptv3_hip import ops
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    data = S.make_batch([n - n // 3, n // 3], in_channels=cin, extent=48, seed=n)
+    off = data["offset"]
+    batch = torch.repeat_interleave(torch.arange(2), torch.diff(off, prepend=torch.zeros(1, dtype=torch.long)))
+    idx = torch.cat([batch[:, None].int(), data["grid_coord"].int()], 1).contiguous()
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(cout, k, k, k, cin, generator=g) / (cin * k ** 3) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = O.subm_conv3d(data["feat"], idx, w, b)
+    nbr, table = ops.subm_neighbors(idx.to(dev), k)
+    # neighbour table is integer work: bit-exact against a dictionary lookup
+    sites = {tuple(r): i for i, r in enumerate(idx.tolist())}
+    nb = nbr.cpu().numpy()
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, n, 200):
+        bb, x, y, z = idx[i].tolist()
+        for d in range(k ** 3):
+            a, b_, c = d // (k * k) - k // 2, (d // k) % k - k // 2, d % k - k // 2
+            assert nb[i, d] == sites.get((bb, x + a, y + b_, z + c), -1)
+    order = torch.randperm(n, generator=g).int()
+    for ro in (None, order.to(dev)):
+        out = ops.gemm(data["feat"].to(dev), w.reshape(cout, -1).contiguous().to(dev), bias=b.to(dev), nbr=nbr,
+                       kvol=k ** 3, row_order=ro)
+        assert (out.cpu() - ref).abs().max().item() < FP32_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,c", [(1, 4), (1000, 32), (333, 48), (257, 64), (100, 256), (65, 512), (9, 2048)])
+def test_layernorm(dev, m, c):
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(m, c, generator=g) * 3 + 1
+    g1, b1, g2, b2 = (torch.randn(c, generator=g) for _ in range(4))
+    res = torch.randn(m, c, generator=g)
+    F = torch.nn.functional
+    y_ref = F.layer_norm(x, (c,), g1, b1, 1e-5) + res
+    y2_ref = F.layer_norm(y_ref, (c,), g2, b2, 1e-5)
+    y, y2 = ops.layernorm(x.to(dev), g1.to(dev), b1.to(dev), 1e-5, res=res.to(dev), gamma2=g2.to(dev), beta2=b2.to(dev))
+    assert (y.cpu() - y_ref).abs().max().item() < FP32_TOL
+    assert (y2.cpu() - y2_ref).abs().max().item() < FP32_TOL
+    y = ops.layernorm(x.to(dev), g1.to(dev), b1.to(dev), 1e-5)
+    assert (y.cpu() - F.layer_norm(x, (c,), g1, b1, 1e-5)).abs().max().item() < FP32_TOL
+
+
+def test_affine_act_and_cast(dev):
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1001, 32, generator=g)
+    s, t = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    y = ops.affine_act(x.to(dev), s.to(dev), t.to(dev), ops.ACT_GELU)
+    assert (y.cpu() - torch.nn.functional.gelu(x * s + t)).abs().max().item() < 1e-5
+    assert torch.equal(ops.cast(x.to(dev), torch.bfloat16).cpu(), x.bfloat16())
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling
+# ------------------------------------------------------------------------------------------------
+def test_pooling_vs_oracle(dev):
+    from ptv3_hip import ops
+    from oracle import sfc
+    import ptv3_scenes as S
+    data = S.make_batch([5000, 3000], in_channels=16, extent=64, seed=11)
+    off = data["offset"]
+    batch = torch.repeat_interleave(torch.arange(2), torch.diff(off, prepend=torch.zeros(1, dtype=torch.long)))
+    code, order, inverse, depth = sfc.serialization(data["grid_coord"].numpy(), batch.numpy(), ORDERS)
+    code_t = torch.from_numpy(code)
+    cluster, seg_start, n_out = ops.pool_segments(code_t[0].contiguous().to(dev),
+                                                  torch.from_numpy(order[0]).contiguous().to(dev), 3)
+    uniq, ref_cluster = torch.unique(code_t[0] >> 3, sorted=True, return_inverse=True)
+    assert n_out == len(uniq)
+    assert torch.equal(cluster.cpu(), ref_cluster)
+    feat_out, coord_out, grid_out, batch_out, code_out = ops.pool_reduce(
+        data["feat"].to(dev), data["coord"].to(dev), data["grid_coord"].to(dev), batch.to(dev), code_t.to(dev),
+        torch.from_numpy(order[0]).contiguous().to(dev), seg_start, n_out, 1)
+    ref_feat = torch.full((n_out, 16), -float("inf")).scatter_reduce(
+        0, ref_cluster[:, None].expand(-1, 16), data["feat"], "amax")
+    assert torch.equal(feat_out.cpu(), ref_feat)
+    cnt = torch.bincount(ref_cluster, minlength=n_out).float()
+    ref_coord = torch.zeros(n_out, 3).index_add_(0, ref_cluster, data["coord"]) / cnt[:, None]
+    assert (coord_out.cpu() - ref_coord).abs().max().item() < 1e-5
+    # parent codes for every order == encode(grid >> 1, depth - 1)
+    ref_code = np.stack([sfc.encode(grid_out.cpu().numpy(), batch_out.cpu().numpy(), depth - 1, o) for o in ORDERS])
+    assert np.array_equal(code_out.cpu().numpy(), ref_code)
+    assert np.array_equal(code_out[0].cpu().numpy(), uniq.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# pointops
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nsample", [1, 3, 16, 70])
+def test_knn_grouping_interpolation_vs_c_oracle(dev, nsample):
+    import pointops
+    from oracle import pointops as OP
+    rng = np.random.default_rng(nsample)
+    xyz = rng.normal(size=(3000, 3)).astype(np.float32)
+    new_xyz = rng.normal(size=(1700, 3)).astype(np.float32)
+    offset = np.array([1000, 1040, 3000], dtype=np.int32)
+    new_offset = np.array([600, 900, 1700], dtype=np.int32)
+    ref_idx, ref_d2 = OP.knn_query(nsample, xyz, offset, new_xyz, new_offset)
+    idx, dist = pointops.knn_query(nsample, torch.from_numpy(xyz).to(dev), torch.from_numpy(offset).to(dev),
+                                   torch.from_numpy(new_xyz).to(dev), torch.from_numpy(new_offset).to(dev))
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(dist.cpu().numpy(), np.sqrt(ref_d2))
+    feat = rng.normal(size=(3000, 20)).astype(np.float32)
+    if nsample <= 16 and (ref_idx >= 0).all():
+        grouped = pointops.grouping2(torch.from_numpy(feat).to(dev), idx)
+        assert np.array_equal(grouped.cpu().numpy(), OP.grouping_forward(feat, ref_idx))
+    if nsample == 3:
+        out = pointops.interpolation(torch.from_numpy(xyz).to(dev), torch.from_numpy(new_xyz).to(dev),
+                                     torch.from_numpy(feat).to(dev), torch.from_numpy(offset).to(dev),
+                                     torch.from_numpy(new_offset).to(dev), k=3)
+        d = np.sqrt(ref_d2)
+        w = (1.0 / (d + 1e-8))
+        w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+        ref = OP.interpolation_forward(feat, ref_idx, w)
+        assert np.abs(out.cpu().numpy() - ref).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# whole model
+# ------------------------------------------------------------------------------------------------
+def _build(cfg, hidden_dim=256):
+    from pointcept.models import build_model
+    return build_model(dict(type="OffsetKeypointPTv3", num_keypoints=6, hidden_dim=hidden_dim,
+                            backbone_conf=dict(type="PT-v3m1", **cfg)))
+
+
+def test_tiny_model_golden(dev, golden_dir):
+    """The reference's own output (tests/golden/ptv3_tiny.npz) reproduced by the HIP model."""
+    g = _g(golden_dir, "ptv3_tiny.npz")
+    model = _build(TINY_CFG, hidden_dim=32)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    data = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    taps = {}
+
+    def mk(name):
+        def hook(m, i, o):
+            taps[name] = o.feat.float().cpu().numpy()
+            if name == "embedding":
+                taps["serialized_code"] = o.serialized_code.cpu().numpy()
+                taps["serialized_order"] = o.serialized_order.cpu().numpy()
+            if name.startswith("enc"):
+                taps[name + "_code"] = o.serialized_code.cpu().numpy()
+                taps[name + "_order"] = o.serialized_order.cpu().numpy()
+                taps[name + "_grid_coord"] = o.grid_coord.cpu().numpy()
+                if "pooling_inverse" in o.keys():
+                    taps[name + "_pooling_inverse"] = o.pooling_inverse.cpu().numpy()
+        return hook
+
+    bb = model.backbone
+    bb.embedding.register_forward_hook(mk("embedding"))
+    for s in range(5):
+        getattr(bb.enc, f"enc{s}").register_forward_hook(mk(f"enc{s}"))
+    for s in range(4):
+        getattr(bb.dec, f"dec{s}").register_forward_hook(mk(f"dec{s}"))
+    torch.manual_seed(int(g["shuffle_seed"]))
+    with torch.no_grad():
+        out = model(data)
+    # integer state: bit exact
+    assert np.array_equal(taps["serialized_code"], g["tap_serialized_code"])
+    assert np.array_equal(taps["serialized_order"], g["tap_serialized_order"])
+    for s in range(5):
+        assert np.array_equal(taps[f"enc{s}_code"], g[f"tap_enc{s}_code"]), s
+        assert np.array_equal(taps[f"enc{s}_order"], g[f"tap_enc{s}_order"]), s
+        assert np.array_equal(taps[f"enc{s}_grid_coord"], g[f"tap_enc{s}_grid_coord"]), s
+        if s > 0:
+            assert np.array_equal(taps[f"enc{s}_pooling_inverse"], g[f"tap_enc{s}_pooling_inverse"]), s
+    for k in ["embedding"] + [f"enc{s}" for s in range(5)] + [f"dec{s}" for s in (3, 2, 1, 0)]:
+        err = np.abs(taps[k] - g["tap_" + k]).max()
+        assert err < FP32_TOL, (k, err)
+    assert np.abs(out["pred"].cpu().numpy() - g["pred"]).max() < FP32_TOL
+    assert abs(out["loss"].item() - float(g["loss"])) < FP32_TOL
+
+
+@pytest.mark.parametrize("sizes,kind,extent", [([12000, 9000], "surface", 128), ([15000], "lidar", 1024)])
+def test_fork_config_vs_oracle(dev, sizes, kind, extent):
+    """configs/my_dataset/offset_keypoint_ptv3.py shape (46M parameters) - HIP model against the oracle
+    on the same seeded weights and scene; keypoint-offset L2 and mask logits within 1e-4."""
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    torch.manual_seed(1234)
+    model = _build(FORK_CFG).eval()
+    gen = torch.Generator().manual_seed(99)
+    for n, b in model.named_buffers():
+        if n.endswith("running_mean"):
+            b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
+        if n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    data = S.make_batch(sizes, in_channels=4, extent=extent, seed=21, kind=kind, with_target=6)
+    orc = O.OffsetKeypointOracle(FORK_CFG, sd)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        ref = orc.forward(data)
+    model = model.to(dev)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out = model({k: v.to(dev) for k, v in data.items()})
+    pred = out["pred"].cpu()
+    l2 = (pred[..., :3] - ref["pred"][..., :3]).norm(dim=-1).max().item()
+    prob = (pred[..., 3] - ref["pred"][..., 3]).abs().max().item()
+    assert l2 < FP32_TOL, l2
+    assert prob < FP32_TOL, prob
+    assert abs(out["loss"].item() - ref["loss"].item()) < FP32_TOL
+    # bf16 mode stays close to the fp32 result (autocast-style run of config[1])
+    model.backbone.compute_dtype = torch.bfloat16
+    torch.manual_seed(5)
+    with torch.no_grad():
+        out16 = model({k: v.to(dev) for k, v in data.items()})
+    rel = (out16["pred"].cpu() - ref["pred"]).abs().mean().item() / ref["pred"].abs().mean().item()
+    assert rel < 0.1, rel
