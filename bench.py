@@ -1,0 +1,186 @@
+"""Headline benchmark: PTv3 (fork config) + keypoint-offset head forward, Mpoints/s.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One step = one eval forward of OffsetKeypointPTv3 (configs/my_dataset/offset_keypoint_ptv3.py shape,
+46.2 M parameters, 1024-point windows) over one synthetic scene batch already resident in HBM.
+Scenes are independent, so N GPUs run N replicas on their own scenes (weak scaling, no data-path
+collective); value = total points / max-over-ranks time.
+Prints ONE JSON line on rank 0 with `roofline` (dominant matrix-core kernel family, HIP-event timed
+inside the timed region) and, at N = 1, `cpu_baseline` (the oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "pointcept-keypointdetection_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points", type=int, default=100000, help="points per scene")
+    ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--kind", default="surface", choices=["surface", "lidar"])
+    ap.add_argument("--cpu-sample", type=int, default=12000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(device):
+    from pointcept.models import build_model
+    from make_golden_cfg import FORK_CFG
+    torch.manual_seed(1234)
+    model = build_model(dict(type="OffsetKeypointPTv3", num_keypoints=6,
+                             backbone_conf=dict(type="PT-v3m1", **FORK_CFG))).eval()
+    gen = torch.Generator().manual_seed(99)
+    for n, b in model.named_buffers():  # non-trivial eval BatchNorm statistics
+        if n.endswith("running_mean"):
+            b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
+        if n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    return model.to(device), sd, FORK_CFG
+
+
+def cpu_baseline(sd, cfg, model, device, n_points):
+    """Oracle (CPU restatement of the reference path) on the host cores + parity of the HIP fp32 path."""
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    data = S.make_batch([n_points], in_channels=4, extent=128, seed=7)
+    orc = O.OffsetKeypointOracle(cfg, sd)
+    torch.manual_seed(11)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = orc.forward(data)
+    dt = time.perf_counter() - t0
+    model.backbone.compute_dtype = torch.float32
+    torch.manual_seed(11)
+    with torch.no_grad():
+        out = model({k: v.to(device) for k, v in data.items()})
+    pred = out["pred"].float().cpu()
+    l2 = (pred[..., :3] - ref["pred"][..., :3]).norm(dim=-1).max().item()
+    lg = (pred[..., 3] - ref["pred"][..., 3]).abs().max().item()
+    return ({"value": round(n_points / dt / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
+             "sample": f"oracle (torch-CPU fp32 restatement) forward of one {n_points}-point surface scene, "
+                       f"{dt:.1f} s wall, {cores} threads"},
+            {"offset_l2_max": l2, "mask_prob_abs_max": lg, "tolerance": 1e-4, "sample_points": n_points,
+             "mode": "fp32"})
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import ptv3_scenes as S
+    from ptv3_hip import ops
+    model, sd, cfg = build_model(device)
+
+    cpu, parity = None, None
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cpu, parity = cpu_baseline(sd, cfg, model, device, args.cpu_sample)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.backbone.compute_dtype = dtype
+    # every rank owns its own scene(s): shard = scene, no exchange on the data path
+    extent = 512 if args.kind == "surface" else 2048
+    batch = S.make_batch([args.points] * args.scenes, in_channels=4, extent=extent, seed=1000 + rank,
+                         kind=args.kind, device="cpu")
+    batch = {k: v.to(device) for k, v in batch.items()}
+    n_points = args.points * args.scenes
+
+    def step():
+        with torch.no_grad():
+            return model(batch)["pred"]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    # HIP events on the launch stream bracket every matrix-core launch INSIDE the timed region
+    ops.PROFILE = None if args.no_kernel_events else []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel-family device time from the events recorded during the timed steps
+    roofline = None
+    if not args.no_kernel_events:
+        prof, ops.PROFILE = ops.PROFILE, None
+        fam = {}
+        for name, e0, e1, work in prof:
+            f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
+            f["ms"] += e0.elapsed_time(e1)
+            f["launches"] += 1
+            f["bytes"] += work["bytes"]
+            if work.get("nbr") is not None:  # algorithmic conv flops count active neighbours only
+                key = work["nbr"].data_ptr()
+                cache = main.__dict__.setdefault("_nnz", {})
+                if key not in cache:
+                    cache[key] = float((work["nbr"] >= 0).sum().item())
+                f["flops"] += 2.0 * cache[key] * work["cin"] * work["cout"]
+            else:
+                f["flops"] += work["flops"]
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        d = fam[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK[args.dtype],
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 5), "traffic": None,
+                    "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"] // args.steps,
+                    "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()}}
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "Mpoints/sec PTv3 fwd @100k pts/scene, 1024-pt window; keypoint offset L2 vs ref",
+            "value": round(n_points * world * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": f"OffsetKeypointPTv3 (PT-v3m1 fork config, 46.2M params) eval forward, "
+                                   f"{args.scenes} x {args.points}-point synthetic {args.kind} scene(s) per GPU, "
+                                   f"patch 1024, serialization + sparse conv + attention + head included",
+                       "points_per_gpu": n_points, "parallelism": f"replicas x{world} (scene-sharded, no collective)"},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
