@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--kind", default="surface", choices=["surface", "lidar"])
-    ap.add_argument("--cpu-sample", type=int, default=12000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=100000, help="points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
     return ap.parse_args()
 
@@ -56,13 +56,25 @@ def build_model(device):
     return model.to(device), sd, FORK_CFG
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask, cgroup quota, capped at the box share."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("PTV3_BENCH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(sd, cfg, model, device, n_points):
     """Oracle (CPU restatement of the reference path) on the host cores + parity of the HIP fp32 path."""
     from oracle import ptv3 as O
     import ptv3_scenes as S
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
-    data = S.make_batch([n_points], in_channels=4, extent=128, seed=7)
+    data = S.make_batch([n_points], in_channels=4, extent=None, seed=7)
     orc = O.OffsetKeypointOracle(cfg, sd)
     torch.manual_seed(11)
     t0 = time.perf_counter()
@@ -106,8 +118,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.backbone.compute_dtype = dtype
     # every rank owns its own scene(s): shard = scene, no exchange on the data path
-    extent = 512 if args.kind == "surface" else 2048
-    batch = S.make_batch([args.points] * args.scenes, in_channels=4, extent=extent, seed=1000 + rank,
+    batch = S.make_batch([args.points] * args.scenes, in_channels=4, extent=None, seed=1000 + rank,
                          kind=args.kind, device="cpu")
     batch = {k: v.to(device) for k, v in batch.items()}
     n_points = args.points * args.scenes

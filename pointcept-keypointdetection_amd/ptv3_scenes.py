@@ -47,8 +47,41 @@ def _lidar_points(rng, n_raw, extent):
     return p * s
 
 
+def _dense_scene(n_points, in_channels, seed, kind):
+    """GridSample-like scene: the surface is sampled densely (every surface voxel hit), the extent is
+    chosen so that about ``n_points`` voxels are occupied, then the small excess is dropped at random.
+    Pools ~4x per stage for kind="surface" (like real voxelised scans), ~1.4x for kind="lidar"."""
+    rng = np.random.default_rng(seed)
+    lo, hi = 16.0, 8192.0
+    for _ in range(24):
+        extent = (lo * hi) ** 0.5
+        sub = np.random.default_rng(seed + 1)
+        fn = _surface_points if kind == "surface" else _lidar_points
+        p = fn(sub, int(n_points * (10 if kind == "surface" else 3)), extent)
+        g = np.floor(p).astype(np.int64)
+        g -= g.min(0)
+        _, first = np.unique(g, axis=0, return_index=True)
+        if len(first) < n_points:
+            lo = extent
+        elif len(first) > 1.04 * n_points:
+            hi = extent
+        else:
+            break
+    if len(first) < n_points:
+        raise RuntimeError("dense scene search failed")
+    sel = first[rng.permutation(len(first))[:n_points]]
+    grid = g[sel]
+    coord = (p[sel] - p[sel].mean(0)).astype(np.float32)
+    coord /= np.abs(coord).max() + 1e-6
+    feat = rng.normal(size=(n_points, in_channels)).astype(np.float32)
+    return {"coord": coord, "grid_coord": grid, "feat": feat}
+
+
 def make_scene(n_points, in_channels=4, extent=256, seed=0, kind="surface"):
-    """One scene with exactly ``n_points`` unique voxels. Returns dict of numpy arrays."""
+    """One scene with exactly ``n_points`` unique voxels. Returns dict of numpy arrays.
+    extent=None: dense mode (see _dense_scene); otherwise a random subset of the voxels inside extent^3."""
+    if extent is None:
+        return _dense_scene(n_points, in_channels, seed, kind)
     rng = np.random.default_rng(seed)
     n_raw = int(n_points * 2.2) + 1024
     for _ in range(8):
