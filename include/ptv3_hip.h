@@ -102,12 +102,15 @@ int ptv3_subm_neighbors(const int32_t* indices, int64_t n, const void* table, in
  *   y2 = y + res[res_index ? res_index[i] : i][o]   (written to `out2` if given, else into `out`);
  * `out` always receives the pre-residual value when out2 != NULL.
  * row_order (optional, (m) int32): output tile t processes rows row_order[64t..] (locality only).
- * x: (rows_x, cin) dtype; out/out2/res: (m|rows, cout) dtype; w/bias/bn_*: see w_dtype (= dtype
- * for w, fp32 for the vectors).  cin % 4 == 0. */
+ * x: (rows_x, cin) dtype; out/out2/res: (m|rows, cout) dtype; w: dtype; bias/bn_*: fp32.
+ * cin % 4 == 0 (fp32) / cin % 8 == 0 (bf16): 16-byte K granularity.
+ * workspace (optional): ptv3_gemm_workspace_bytes(...) bytes of split-K slab room; shapes with few
+ * rows and a long K (deep-stage convolutions) are then split over K and summed in slab order. */
+size_t ptv3_gemm_workspace_bytes(int64_t m, int cin, int cout, int kvol, int dtype);
 int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int cin, int cout, int kvol,
               const int32_t* nbr, const int32_t* row_order, const float* bias, const float* bn_scale,
               const float* bn_shift, int act, const void* res, const int32_t* res_index, void* out2,
-              int dtype, void* stream);
+              int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- normalisation / elementwise -------------------------------------------------------------
  * torch.nn.LayerNorm over the last dim (Block.cpe[2], norm1, norm2; :277-304): y = LN(x)*g+b [+ res];
@@ -131,11 +134,13 @@ int ptv3_cast(const void* x, int src_dtype, void* y, int dst_dtype, int64_t coun
  * step 1 (segments): cluster[i] (n) int64 = rank of the parent code; seg_start (n+1) int32 run starts
  *         in order0 positions (first *n_out+1 entries valid); n_out written to device AND the
  *         caller reads it back (the one host sync per pooling, as torch.unique has).
- *         workspace: ptv3_pool_workspace_bytes(n). */
+ *         batch (n) int64 + pooled_offset (b) int64 (both optional): cumulative scene ends of the
+ *         pooled Point (= batch2offset(batch[head]), models/utils/misc.py:32-34); pooled_offset[b-1]
+ *         equals n_out.  workspace: ptv3_pool_workspace_bytes(n). */
 size_t ptv3_pool_workspace_bytes(int64_t n);
 int ptv3_pool_segments(const int64_t* code0, const int64_t* order0, int64_t n, int shift_bits,
-                       int64_t* cluster, int32_t* seg_start, int32_t* n_out, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       const int64_t* batch, int64_t* cluster, int32_t* seg_start, int32_t* n_out,
+                       int64_t* pooled_offset, void* workspace, size_t workspace_bytes, void* stream);
 /* step 2 (reduce): for pooled row j over members order0[seg_start[j] .. seg_start[j+1]):
  *   feat_out[j]  = act(max_members(feat[.]) * bn_scale + bn_shift)        (n_out, c) dtype
  *   coord_out[j] = mean_members(coord[.])                                  (n_out, 3) fp32

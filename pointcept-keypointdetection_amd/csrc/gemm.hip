@@ -1,9 +1,12 @@
 // Implicit-GEMM kernel shared by torch.nn.Linear and the submanifold sparse convolution:
 //   out[i][o] = epilogue( sum_{d<kvol} sum_{c<cin} w[o][d][c] * x[nbr[i][d]][c] )
 // (kvol = 1 and nbr = NULL gives the dense linear).  Rows of x are gathered straight into the
-// LDS A-tile, weights stream through the LDS B-tile, both K-contiguous, so every matrix-core
-// fragment is one 4-element LDS read.  Product is computed transposed (W_tile * X_tile^T) so each
-// lane ends up with 4 consecutive output channels of ONE point: vector epilogue + 16-B stores.
+// LDS A-tile, weights stream through the LDS B-tile, both K-contiguous, 16 bytes per lane per
+// access, so every matrix-core fragment is one ds_read_b128.  The product is computed transposed
+// (W_tile * X_tile^T) so each lane ends up with 4 consecutive output channels of ONE point:
+// vector epilogue + wide stores.  Small-M / huge-K shapes (deep-stage convolutions: M ~ 10^2..10^3
+// rows against K = 27*C up to 13824) are split over K into fp32 slabs that a second kernel sums in
+// slab order (bitwise reproducible) and finishes with the same epilogue.
 // Reference semantics: include/ptv3_hip.h (ptv3_gemm).
 #include "common.h"
 #include "../../include/ptv3_hip.h"
@@ -11,15 +14,39 @@
 namespace ptv3 {
 
 constexpr int GM_THREADS = 256;
-constexpr int GM_BM = 64;   // points per workgroup (4 waves x 16)
-constexpr int GM_BK = 32;   // K elements per LDS stage
-constexpr int GM_LS = GM_BK + 4;  // LDS row stride (elements)
+constexpr int GM_BM = 64;  // points per workgroup (4 waves x 16)
+
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 16-byte fragment of T: 4 fp32 or 8 bf16 consecutive K elements
+template <typename T> struct Frag;
+template <> struct Frag<float> {
+  typedef f32x4 type;
+  static constexpr int E = 4;    // elements per lane per fragment
+  static constexpr int KC = 16;  // K covered by one matrix-core chunk (4 lane groups x E)
+  static __device__ __forceinline__ f32x4 zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // 4 x v_mfma_f32_16x16x4_f32: exact fp32 fma chain
+  static __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) { return mma16<float>(a, b, c); }
+};
+template <> struct Frag<__bf16> {
+  typedef s16x8 type;
+  static constexpr int E = 8;
+  static constexpr int KC = 32;
+  static __device__ __forceinline__ s16x8 zero() { return s16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+  // 1 x v_mfma_f32_16x16x32_bf16: lane (i, g) holds A[i][8g..8g+7], B[8g..8g+7][i]
+  static __device__ __forceinline__ f32x4 mma(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                   0, 0, 0);
+  }
+};
 
 struct GemmArgs {
   const void* x; const void* w; void* out; void* out2; const void* res;
   const int32_t* nbr; const int32_t* row_order; const int32_t* res_index;
   const float* bias; const float* bn_scale; const float* bn_shift;
-  int64_t m; int cin; int cout; int kvol; int act;
+  float* slab;  // split-K partial sums [splits][m][cout] fp32 (NULL: direct epilogue)
+  int64_t m; int cin; int cout; int kvol; int act; int cin_shift; int steps_per_split;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -28,14 +55,74 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
+// bias -> folded BN -> activation -> (indexed) residual -> store(s) for 4 consecutive channels of one row
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& a, int64_t orow, int ch0, const float* accv) {
+  typedef typename Vec4<T>::type V4;
+  T* out = reinterpret_cast<T*>(a.out);
+  T* out2 = reinterpret_cast<T*>(a.out2);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  const bool vec_ok = (a.cout & 3) == 0;
+  float v[4], v2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ch = ch0 + r;
+    float t = accv[r];
+    if (ch < a.cout) {
+      if (a.bias) t += a.bias[ch];
+      if (a.bn_scale) t = t * a.bn_scale[ch] + a.bn_shift[ch];
+      t = apply_act(t, a.act);
+    }
+    v[r] = t;
+    v2[r] = t;
+  }
+  if (a.res) {
+    const int64_t rrow = a.res_index ? (int64_t)a.res_index[orow] : orow;
+    if (vec_ok) {
+      float rr[4];
+      unpack4<T>(*reinterpret_cast<const V4*>(res + rrow * a.cout + ch0), rr);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v2[r] = v[r] + rr[r];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (ch0 + r < a.cout) v2[r] = v[r] + to_f32<T>(res[rrow * a.cout + ch0 + r]);
+    }
+  }
+  if (vec_ok) {
+    if (out2) {
+      *reinterpret_cast<V4*>(out + orow * a.cout + ch0) = pack4<T>(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<V4*>(out2 + orow * a.cout + ch0) = pack4<T>(v2[0], v2[1], v2[2], v2[3]);
+    } else {
+      *reinterpret_cast<V4*>(out + orow * a.cout + ch0) = pack4<T>(v2[0], v2[1], v2[2], v2[3]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (ch0 + r < a.cout) {
+        if (out2) {
+          out[orow * a.cout + ch0 + r] = from_f32<T>(v[r]);
+          out2[orow * a.cout + ch0 + r] = from_f32<T>(v2[r]);
+        } else {
+          out[orow * a.cout + ch0 + r] = from_f32<T>(v2[r]);
+        }
+      }
+  }
+}
+
 template <typename T, int BN>
 __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
-  typedef typename Vec4<T>::type V4;
-  constexpr int NT = BN / 16;                                  // 16-channel tiles per wave
-  constexpr int A_LOADS = (GM_BM * (GM_BK / 4)) / GM_THREADS;  // 2
-  constexpr int B_LOADS = (BN * (GM_BK / 4)) / GM_THREADS;     // BN/32
-  __shared__ __attribute__((aligned(16))) T sA[GM_BM * GM_LS];
-  __shared__ __attribute__((aligned(16))) T sB[BN * GM_LS];
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  constexpr int E = F::E;
+  constexpr int BK = 2 * F::KC;      // K elements per LDS stage = 128 bytes per row
+  constexpr int LS = BK + E;         // LDS row stride (elements): +16 bytes keeps ds_read_b128 conflict-free
+  constexpr int CPR = BK / E;        // 16-byte chunks per row (8)
+  constexpr int NT = BN / 16;        // 16-channel tiles per wave
+  constexpr int A_LOADS = (GM_BM * CPR) / GM_THREADS;  // 2
+  constexpr int B_LOADS = (BN * CPR) / GM_THREADS;     // BN/32
+  __shared__ __attribute__((aligned(16))) T sA[GM_BM * LS];
+  __shared__ __attribute__((aligned(16))) T sB[BN * LS];
 
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
@@ -44,16 +131,21 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   const int64_t row0 = (int64_t)blockIdx.x * GM_BM;
   const int n0 = blockIdx.y * BN;
   const int ktot = a.kvol * a.cin;
-  const int nsteps = (ktot + GM_BK - 1) / GM_BK;
+  const int nsteps = (ktot + BK - 1) / BK;
+  int step_lo = 0, step_hi = nsteps;
+  if (a.slab) {
+    step_lo = blockIdx.z * a.steps_per_split;
+    step_hi = min(nsteps, step_lo + a.steps_per_split);
+  }
 
-  // A staging: chunk e -> (row e/8, 4-element chunk e%8); both chunks of a thread sit in one row
+  // A staging: chunk e -> (row e / CPR, chunk e % CPR); the chunks of one thread sit in one row
   int64_t arow[A_LOADS];
   int a_r[A_LOADS], a_ch[A_LOADS];
 #pragma unroll
   for (int u = 0; u < A_LOADS; ++u) {
     int e = tid * A_LOADS + u;
-    a_r[u] = e / (GM_BK / 4);
-    a_ch[u] = e % (GM_BK / 4);
+    a_r[u] = e / CPR;
+    a_ch[u] = e % CPR;
     int64_t r = row0 + a_r[u];
     if (r < a.m) arow[u] = a.row_order ? (int64_t)a.row_order[r] : r; else arow[u] = -1;
   }
@@ -61,59 +153,59 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
 #pragma unroll
   for (int u = 0; u < B_LOADS; ++u) {
     int e = tid * B_LOADS + u;
-    b_r[u] = e / (GM_BK / 4);
-    b_ch[u] = e % (GM_BK / 4);
+    b_r[u] = e / CPR;
+    b_ch[u] = e % CPR;
   }
 
-  V4 ra[A_LOADS], rb[B_LOADS];
+  FR ra[A_LOADS], rb[B_LOADS];
   auto issue = [&](int step) {
-    const int k0 = step * GM_BK;
+    const int k0 = step * BK;
 #pragma unroll
     for (int u = 0; u < A_LOADS; ++u) {
-      ra[u] = zero4<T>();
-      int kk = k0 + 4 * a_ch[u];
+      ra[u] = F::zero();
+      int kk = k0 + E * a_ch[u];
       if (arow[u] >= 0 && kk < ktot) {
         int64_t src = arow[u];
         int c = kk;
         if (a.nbr) {
-          int d = kk / a.cin;
+          int d = a.cin_shift >= 0 ? (kk >> a.cin_shift) : (kk / a.cin);
           c = kk - d * a.cin;
           src = a.nbr[arow[u] * a.kvol + d];
         }
-        if (src >= 0) ra[u] = *reinterpret_cast<const V4*>(x + src * a.cin + c);
+        if (src >= 0) ra[u] = *reinterpret_cast<const FR*>(x + src * a.cin + c);
       }
     }
 #pragma unroll
     for (int u = 0; u < B_LOADS; ++u) {
-      rb[u] = zero4<T>();
-      int kk = k0 + 4 * b_ch[u];
+      rb[u] = F::zero();
+      int kk = k0 + E * b_ch[u];
       int o = n0 + b_r[u];
-      if (o < a.cout && kk < ktot) rb[u] = *reinterpret_cast<const V4*>(w + (int64_t)o * ktot + kk);
+      if (o < a.cout && kk < ktot) rb[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
     }
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int u = 0; u < A_LOADS; ++u) *reinterpret_cast<V4*>(sA + a_r[u] * GM_LS + 4 * a_ch[u]) = ra[u];
+    for (int u = 0; u < A_LOADS; ++u) *reinterpret_cast<FR*>(sA + a_r[u] * LS + E * a_ch[u]) = ra[u];
 #pragma unroll
-    for (int u = 0; u < B_LOADS; ++u) *reinterpret_cast<V4*>(sB + b_r[u] * GM_LS + 4 * b_ch[u]) = rb[u];
+    for (int u = 0; u < B_LOADS; ++u) *reinterpret_cast<FR*>(sB + b_r[u] * LS + E * b_ch[u]) = rb[u];
   };
 
   f32x4 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  for (int step = 0; step < nsteps; ++step) {
+  if (step_lo < step_hi) issue(step_lo);
+  for (int step = step_lo; step < step_hi; ++step) {
     stash();
     __syncthreads();
-    if (step + 1 < nsteps) issue(step + 1);
+    if (step + 1 < step_hi) issue(step + 1);
 #pragma unroll
-    for (int ks = 0; ks < GM_BK / 16; ++ks) {
-      V4 xf = *reinterpret_cast<const V4*>(sA + (16 * wave + li) * GM_LS + 16 * ks + 4 * g);
+    for (int ks = 0; ks < 2; ++ks) {
+      FR xf = *reinterpret_cast<const FR*>(sA + (16 * wave + li) * LS + F::KC * ks + E * g);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        V4 wf = *reinterpret_cast<const V4*>(sB + (16 * j + li) * GM_LS + 16 * ks + 4 * g);
-        acc[j] = mma16<T>(wf, xf, acc[j]);  // D[channel 4g+r][point li]
+        FR wf = *reinterpret_cast<const FR*>(sB + (16 * j + li) * LS + F::KC * ks + E * g);
+        acc[j] = F::mma(wf, xf, acc[j]);  // D[channel 4g+r][point li]
       }
     }
     __syncthreads();
@@ -123,87 +215,122 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   const int64_t prow = row0 + 16 * wave + li;
   if (prow >= a.m) return;
   const int64_t orow = a.row_order ? (int64_t)a.row_order[prow] : prow;
-  T* out = reinterpret_cast<T*>(a.out);
-  T* out2 = reinterpret_cast<T*>(a.out2);
-  const T* res = reinterpret_cast<const T*>(a.res);
-  const int64_t rrow = a.res ? (a.res_index ? (int64_t)a.res_index[orow] : orow) : 0;
-  const bool vec_ok = (a.cout & 3) == 0;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ch0 = n0 + 16 * j + 4 * g;
     if (ch0 >= a.cout) continue;
-    float v[4], v2[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ch = ch0 + r;
-      float t = acc[j][r];
-      if (ch < a.cout) {
-        if (a.bias) t += a.bias[ch];
-        if (a.bn_scale) t = t * a.bn_scale[ch] + a.bn_shift[ch];
-        t = apply_act(t, a.act);
-      }
-      v[r] = t;
-      v2[r] = t;
-    }
-    if (a.res) {
-      if (vec_ok) {
-        float rr[4];
-        unpack4<T>(*reinterpret_cast<const V4*>(res + rrow * a.cout + ch0), rr);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v2[r] = v[r] + rr[r];
+    if (a.slab) {
+      float* dst = a.slab + ((int64_t)blockIdx.z * a.m + orow) * a.cout + ch0;
+      if ((a.cout & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst) = acc[j];
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (ch0 + r < a.cout) v2[r] = v[r] + to_f32<T>(res[rrow * a.cout + ch0 + r]);
+          if (ch0 + r < a.cout) dst[r] = acc[j][r];
       }
+    } else {
+      float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+      epilogue_store<T>(a, orow, ch0, v);
     }
+  }
+}
+
+// sums the split-K slabs in slab order and applies the epilogue: one thread per (row, 4 channels)
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int splits) {
+  const int c4 = (a.cout + 3) / 4;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.m * c4) return;
+  const int64_t row = t / c4;
+  const int ch0 = (int)(t - row * c4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec_ok = (a.cout & 3) == 0;
+  for (int z = 0; z < splits; ++z) {
+    const float* src = a.slab + ((int64_t)z * a.m + row) * a.cout + ch0;
     if (vec_ok) {
-      if (out2) {
-        *reinterpret_cast<V4*>(out + orow * a.cout + ch0) = pack4<T>(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<V4*>(out2 + orow * a.cout + ch0) = pack4<T>(v2[0], v2[1], v2[2], v2[3]);
-      } else {
-        *reinterpret_cast<V4*>(out + orow * a.cout + ch0) = pack4<T>(v2[0], v2[1], v2[2], v2[3]);
-      }
+      f32x4 p = *reinterpret_cast<const f32x4*>(src);
+      v[0] += p[0]; v[1] += p[1]; v[2] += p[2]; v[3] += p[3];
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (ch0 + r < a.cout) {
-          if (out2) {
-            out[orow * a.cout + ch0 + r] = from_f32<T>(v[r]);
-            out2[orow * a.cout + ch0 + r] = from_f32<T>(v2[r]);
-          } else {
-            out[orow * a.cout + ch0 + r] = from_f32<T>(v2[r]);
-          }
-        }
+        if (ch0 + r < a.cout) v[r] += src[r];
     }
   }
+  epilogue_store<T>(a, row, ch0, v);
+}
+
+static int bk_of(int dtype) { return dtype == PTV3_F32 ? 32 : 64; }
+
+// split decision shared by the workspace query and the launcher
+static int choose_splits(int64_t m, int cin, int cout, int kvol, int dtype, int* steps_per_split) {
+  const int bk = bk_of(dtype);
+  const int64_t ktot = (int64_t)kvol * cin;
+  const int nsteps = (int)((ktot + bk - 1) / bk);
+  const int bn = (cout % 64 == 0) ? 64 : 32;
+  const int64_t base = cdiv(m, GM_BM) * cdiv(cout, bn);
+  int splits = 1;
+  if (nsteps >= 8 && base < 1024) {
+    int64_t want = 2048 / base;
+    if (want > nsteps / 4) want = nsteps / 4;
+    if (want > 1) splits = (int)want;
+  }
+  int sps = (nsteps + splits - 1) / splits;
+  splits = (nsteps + sps - 1) / sps;
+  *steps_per_split = sps;
+  return splits;
 }
 
 }  // namespace ptv3
 
 using namespace ptv3;
 
+extern "C" size_t ptv3_gemm_workspace_bytes(int64_t m, int cin, int cout, int kvol, int dtype) {
+  int sps;
+  int splits = choose_splits(m, cin, cout, kvol, dtype, &sps);
+  return splits > 1 ? (size_t)splits * m * cout * sizeof(float) : 0;
+}
+
 extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int cin, int cout, int kvol,
                          const int32_t* nbr, const int32_t* row_order, const float* bias,
                          const float* bn_scale, const float* bn_shift, int act, const void* res,
-                         const int32_t* res_index, void* out2, int dtype, void* stream) {
-  PTV3_REQUIRE(cin > 0 && cin % 4 == 0, "gemm: cin=%d must be a positive multiple of 4", cin);
+                         const int32_t* res_index, void* out2, int dtype, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "gemm: bad dtype %d", dtype);
+  const int gran = dtype == PTV3_F32 ? 4 : 8;
+  PTV3_REQUIRE(cin > 0 && cin % gran == 0, "gemm: cin=%d must be a positive multiple of %d for this dtype", cin, gran);
   PTV3_REQUIRE(cout > 0, "gemm: cout=%d", cout);
   PTV3_REQUIRE(kvol >= 1 && (kvol == 1 || nbr != nullptr), "gemm: kvol=%d needs a neighbour table", kvol);
   PTV3_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "gemm: bn_scale/bn_shift must come together");
-  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "gemm: bad dtype %d", dtype);
   PTV3_REQUIRE(out2 == nullptr || res != nullptr, "gemm: out2 without res");
   if (m == 0) return PTV3_OK;
-  GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift, m, cin, cout, kvol, act};
+  int sps;
+  int splits = choose_splits(m, cin, cout, kvol, dtype, &sps);
+  if (splits > 1 && (workspace == nullptr || workspace_bytes < (size_t)splits * m * cout * sizeof(float))) {
+    splits = 1;  // caller gave no slab room: single pass
+    sps = 0;
+  }
+  int cin_shift = -1;
+  if ((cin & (cin - 1)) == 0) { cin_shift = 0; while ((1 << cin_shift) < cin) ++cin_shift; }
+  GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
+             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps};
   hipStream_t s = (hipStream_t)stream;
   const int bn = (cout % 64 == 0) ? 64 : 32;
-  dim3 grid((unsigned)cdiv(m, GM_BM), (unsigned)cdiv(cout, bn));
+  dim3 grid((unsigned)cdiv(m, GM_BM), (unsigned)cdiv(cout, bn), (unsigned)splits);
   if (dtype == PTV3_F32) {
     if (bn == 64) hipLaunchKernelGGL((gemm_kernel<float, 64>), grid, dim3(GM_THREADS), 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<float, 32>), grid, dim3(GM_THREADS), 0, s, a);
   } else {
     if (bn == 64) hipLaunchKernelGGL((gemm_kernel<__bf16, 64>), grid, dim3(GM_THREADS), 0, s, a);
     else hipLaunchKernelGGL((gemm_kernel<__bf16, 32>), grid, dim3(GM_THREADS), 0, s, a);
+  }
+  if (splits > 1) {
+    GemmArgs r = a;
+    r.row_order = nullptr;  // slabs are indexed by output row already
+    const int64_t work = m * ((cout + 3) / 4);
+    if (dtype == PTV3_F32)
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
   }
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;

@@ -83,13 +83,21 @@ __global__ void __launch_bounds__(PS_THREADS)
 pool_assign_kernel(const int64_t* __restrict__ code0, const int64_t* __restrict__ order0, int64_t n, int shift,
                    const uint32_t* __restrict__ local_scan, const uint32_t* __restrict__ block_excl,
                    const int32_t* __restrict__ n_out, int64_t* __restrict__ cluster,
-                   int32_t* __restrict__ seg_start) {
+                   int32_t* __restrict__ seg_start, const int64_t* __restrict__ batch,
+                   int64_t* __restrict__ pooled_offset) {
   int64_t i = (int64_t)blockIdx.x * PS_THREADS + threadIdx.x;
   if (i >= n) return;
   uint32_t cid = local_scan[i] + block_excl[i / PS_TILE] - 1u;
-  cluster[order0[i]] = (int64_t)cid;
+  const int64_t pt = order0[i];
+  cluster[pt] = (int64_t)cid;
   if (pool_flag(code0, order0, i, shift)) seg_start[cid] = (int32_t)i;
   if (i == n - 1) seg_start[*n_out] = (int32_t)n;
+  if (batch) {
+    // codes carry the batch id in their top bits, so scenes are contiguous along order0: the last point
+    // of scene b closes it at pooled row cid + 1 (cumulative "offset" of the pooled Point)
+    const int64_t b = batch[pt];
+    if (i == n - 1 || batch[order0[i + 1]] != b) pooled_offset[b] = (int64_t)cid + 1;
+  }
 }
 
 // LPR lanes per pooled row over the channel chunks; max over the members, then folded BN + act
@@ -165,8 +173,10 @@ extern "C" size_t ptv3_pool_workspace_bytes(int64_t n) {
 }
 
 extern "C" int ptv3_pool_segments(const int64_t* code0, const int64_t* order0, int64_t n, int shift_bits,
-                                  int64_t* cluster, int32_t* seg_start, int32_t* n_out, void* workspace,
-                                  size_t workspace_bytes, void* stream) {
+                                  const int64_t* batch, int64_t* cluster, int32_t* seg_start, int32_t* n_out,
+                                  int64_t* pooled_offset, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  PTV3_REQUIRE((batch == nullptr) == (pooled_offset == nullptr), "pool_segments: batch and pooled_offset come together");
   PTV3_REQUIRE(n >= 1 && n < (1ll << 31), "pool_segments: n=%lld", (long long)n);
   PTV3_REQUIRE(shift_bits >= 0 && shift_bits < 63, "pool_segments: shift_bits");
   PTV3_REQUIRE(workspace_bytes >= ptv3_pool_workspace_bytes(n), "pool_segments: workspace too small");
@@ -178,7 +188,7 @@ extern "C" int ptv3_pool_segments(const int64_t* code0, const int64_t* order0, i
                      local_scan, bsum);
   hipLaunchKernelGGL(pool_block_scan_kernel, dim3(1), dim3(1024), 0, s, bsum, nblk, n_out);
   hipLaunchKernelGGL(pool_assign_kernel, dim3((unsigned)cdiv(n, PS_THREADS)), dim3(PS_THREADS), 0, s, code0,
-                     order0, n, shift_bits, local_scan, bsum, n_out, cluster, seg_start);
+                     order0, n, shift_bits, local_scan, bsum, n_out, cluster, seg_start, batch, pooled_offset);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

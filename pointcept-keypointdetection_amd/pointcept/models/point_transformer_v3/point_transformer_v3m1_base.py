@@ -265,7 +265,9 @@ class SerializedPooling(PointModule):
         code = point.serialized_code
         order0 = point.serialized_order[0]
         # clusters = runs of equal (code[0] >> 3*pooling_depth) along serialized order 0
-        cluster, seg_start, n_out = ops.pool_segments(code[0], order0, pooling_depth * 3)
+        nb = len(point.offset)
+        cluster, seg_start, n_out, pooled_offset, pooled_offset_host = ops.pool_segments(
+            code[0], order0, pooling_depth * 3, batch=point.batch.long().contiguous(), num_scenes=nb)
         k = code.shape[0]
         if self.shuffle_orders:
             # same CPU-RNG draw as the reference (:408-412); applied to the source rows so the pooled codes
@@ -289,13 +291,12 @@ class SerializedPooling(PointModule):
             point.grid_coord.long().contiguous(), point.batch.long().contiguous(), code_src, order0, seg_start,
             n_out, pooling_depth, bn_scale=scale, bn_shift=shift, act=act_id if fuse else ops.ACT_NONE)
         depth = point.serialized_depth - pooling_depth
-        nb = len(point.offset)
         end_bit = max(1, depth * 3 + max(nb - 1, 0).bit_length())
         order, inverse = ops.argsort_codes(code_out, end_bit)
         point_dict = Point(
             feat=feat, coord=coord, grid_coord=grid_coord, serialized_code=code_out, serialized_order=order,
-            serialized_inverse=inverse, serialized_depth=depth, batch=batch,
-            offset=torch.cumsum(torch.bincount(batch, minlength=nb), dim=0).long(),
+            serialized_inverse=inverse, serialized_depth=depth, batch=batch, offset=pooled_offset,
+            _offset_host=pooled_offset_host,
         )
         if coord is None:
             del point_dict["coord"]

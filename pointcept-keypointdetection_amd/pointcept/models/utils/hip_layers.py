@@ -46,9 +46,9 @@ class Linear(nn.Linear):
         return self._cache.get("b", [self.bias], lambda: _f32(self.bias))
 
     def forward(self, x, **epilogue):
-        pad = (-x.shape[1]) % 4
+        pad = (-x.shape[1]) % ops.k_granule(x.dtype)
         w = self.weight_for(x.dtype)
-        if pad:  # 4-channel granularity of the kernel
+        if pad:  # 16-byte K granularity of the kernel
             x = torch.nn.functional.pad(x, (0, pad)).contiguous()
             w = torch.nn.functional.pad(w, (0, pad)).contiguous()
         return ops.gemm(x, w, bias=self.bias_f32(), **epilogue)

@@ -94,8 +94,9 @@ class SubMConv3d(nn.Module):
     def forward(self, x: SparseConvTensor, bn_scale=None, bn_shift=None, act=ops.ACT_NONE):
         feat = x.features
         cin = feat.shape[1]
-        cin_pad = (cin + 3) // 4 * 4
-        if cin_pad != cin:  # kernel wants 4-channel granularity: zero-pad features and weights alike
+        gran = ops.k_granule(feat.dtype)
+        cin_pad = (cin + gran - 1) // gran * gran
+        if cin_pad != cin:  # kernel wants 16-byte K granularity: zero-pad features and weights alike
             feat = torch.nn.functional.pad(feat, (0, cin_pad - cin)).contiguous()
         nbr = x.neighbors(self.kernel_size, self.indice_key)
         w = self._weight_for(feat.dtype, cin_pad)

@@ -28,12 +28,14 @@ SIGNATURES = {
     "ptv3_subm_table_slots": (c_int64, [c_int64]),
     "ptv3_subm_build_table": (c_int, [P, c_int64, P, c_int64, P]),
     "ptv3_subm_neighbors": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),
-    "ptv3_gemm": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, c_int, P]),
+    "ptv3_gemm_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "ptv3_gemm": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, c_int, P, c_size_t,
+                          P]),
     "ptv3_layernorm": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     "ptv3_affine_act": (c_int, [P, P, P, c_int, P, c_int64, c_int, c_int, P]),
     "ptv3_cast": (c_int, [P, c_int, P, c_int, c_int64, P]),
     "ptv3_pool_workspace_bytes": (c_size_t, [c_int64]),
-    "ptv3_pool_segments": (c_int, [P, P, c_int64, c_int, P, P, P, P, c_size_t, P]),
+    "ptv3_pool_segments": (c_int, [P, P, c_int64, c_int, P, P, P, P, P, P, c_size_t, P]),
     "ptv3_pool_reduce": (c_int, [P, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, P, P, c_int, P, P, P,
                                  P, P, c_int, P]),
     "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),

@@ -33,8 +33,11 @@ def test_argument_validation_without_gpu():
     from ptv3_hip.lib import lib
     rc = lib.ptv3_window_attn_fwd(None, None, None, None, 10, 10, 30, 4, 5, 0.25, None, 0, None)
     assert rc != 0 and b"not divisible" in lib.ptv3_last_error()
-    rc = lib.ptv3_gemm(None, None, None, 5, 6, 8, 1, None, None, None, None, None, 0, None, None, None, 0, None)
+    rc = lib.ptv3_gemm(None, None, None, 5, 6, 8, 1, None, None, None, None, None, 0, None, None, None, 0, None, 0,
+                       None)
     assert rc != 0 and b"multiple of 4" in lib.ptv3_last_error()
+    assert lib.ptv3_gemm_workspace_bytes(100000, 64, 192, 1, 1) == 0      # large M: single pass
+    assert lib.ptv3_gemm_workspace_bytes(245, 512, 512, 27, 1) > 0        # deep-stage conv: split over K
     assert lib.ptv3_argsort_workspace_bytes(4, 100000) > 4 * 100000 * 24
     assert lib.ptv3_subm_table_slots(100000) == 262144
 
