@@ -134,7 +134,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     # HIP events on the launch stream bracket every matrix-core launch INSIDE the timed region
-    ops.PROFILE = None if args.no_kernel_events else []
+    if not args.no_kernel_events:
+        ops.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -151,28 +152,18 @@ def main():
     # ---- per-kernel-family device time from the events recorded during the timed steps
     roofline = None
     if not args.no_kernel_events:
-        prof, ops.PROFILE = ops.PROFILE, None
-        fam = {}
-        for name, e0, e1, work in prof:
-            f = fam.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
-            f["ms"] += e0.elapsed_time(e1)
-            f["launches"] += 1
-            f["bytes"] += work["bytes"]
-            if work.get("nbr") is not None:  # algorithmic conv flops count active neighbours only
-                key = work["nbr"].data_ptr()
-                cache = main.__dict__.setdefault("_nnz", {})
-                if key not in cache:
-                    cache[key] = float((work["nbr"] >= 0).sum().item())
-                f["flops"] += 2.0 * cache[key] * work["cin"] * work["cout"]
-            else:
-                f["flops"] += work["flops"]
+        fam = ops.profile_collect()
+        ops.profile_enable(False)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK[args.dtype],
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 5), "traffic": None,
-                    "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "launches_per_step": d["launches"] // args.steps,
-                    "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()}}
+                    "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
+                    "launches_per_step": d["launches"] // args.steps,
+                    "algorithmic_gflop_per_step": round(d["flops"] / args.steps / 1e9, 3),
+                    "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()},
+                    "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()}}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

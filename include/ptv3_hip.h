@@ -153,6 +153,57 @@ int ptv3_pool_reduce(const void* feat, const float* coord, const int64_t* grid_c
                      float* coord_out, int64_t* grid_out, int64_t* batch_out, int64_t* code_out,
                      int dtype, void* stream);
 
+/* ---- whole-model forward ------------------------------------------------------------------------
+ * PointTransformerV3.forward (point_transformer_v3m1_base.py:699-714) in eval mode, optionally followed by
+ * the dense keypoint-offset head (offset_keypoint_ptv3.py:26-31), as one call: every kernel above is
+ * launched back to back from native code.  Used by pointcept.models (PT-v3m1) as its fast path; results
+ * are identical to composing the per-op entry points.
+ * params: flat table of device pointers in module order -
+ *   stem conv w, stem BN scale, shift;
+ *   per encoder stage s: [s>0: down.proj w, b, BN scale, shift] then per block the 18 pointers
+ *     cpe conv w, b, cpe linear w, b, cpe LN g, b, norm1 g, b, qkv w, b, proj w, b, norm2 g, b,
+ *     fc1 w, b, fc2 w, b;
+ *   per decoder stage s = S-2..0: up.proj w, b, BN scale, shift, up.proj_skip w, b, BN scale, shift, blocks;
+ *   head (if head_out > 0): linear0 w, b, BN scale, shift, linear1 w, b.
+ *   matrices in `dtype` (conv weights (cout, kvol, cin) with cin padded to the 16-byte granule),
+ *   vectors fp32, BatchNorm folded to (scale, shift). */
+typedef struct {
+  int32_t dtype, in_channels /* padded */, num_stages, num_orders;
+  int32_t enc_depths[8], enc_channels[8], enc_heads[8], enc_patch[8];
+  int32_t dec_depths[8], dec_channels[8], dec_heads[8], dec_patch[8];
+  int32_t stride[8];
+  int32_t enc_mode, enable_flash; /* enable_flash = 0: patch = min(smallest scene, patch) (:173-176) */
+  int32_t head_hidden, head_out;  /* head_out = 0: backbone only */
+  float mlp_ratio, ln_eps, qk_scale /* 0: (c/heads)^-0.5 */;
+} ptv3_model_desc;
+
+typedef struct {
+  const void* grid_coord; int32_t coord_is_i64; /* (n,3) */
+  const void* feat;                             /* (n, in_channels) dtype */
+  const int64_t* batch;                         /* (n) */
+  const int64_t* offset;                        /* (b) cumulative, device */
+  const int64_t* offset_host;                   /* (b) same values, host */
+  int32_t b; int64_t n; int32_t depth;          /* depth = bit_length(max(grid_coord)+1) (structure.py:73) */
+  const int32_t* order_ids_host;                /* num_orders curve ids, already in shuffled order */
+  const int32_t* pool_perm_host;                /* (num_stages-1, num_orders) row permutations (:408-412) */
+  int64_t *code, *order, *inverse;              /* out: (num_orders, n) level-0 serialization */
+  void* out_feat;                               /* out: (n, dec_channels[0]) dtype */
+  float* out_head;                              /* out: (n, head_out) fp32 (head_out > 0) */
+  int64_t* stage_points_host;                   /* out, optional: num_stages point counts */
+} ptv3_forward_io;
+
+size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b);
+int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
+                 const ptv3_forward_io* io, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- measurement ---------------------------------------------------------------------------------
+ * While enabled, ptv3_gemm and ptv3_window_attn_fwd bracket their launches with HIP events on the launch
+ * stream.  collect() synchronises the device and returns, per kernel family (0 linear, 1 subm_conv,
+ * 2 window_attn): summed device milliseconds, algorithmic flops (sparse conv: 2*cin*cout per ACTIVE
+ * neighbour), algorithmic bytes and launch count since enable / the last collect. */
+int ptv3_profile_enable(int on);
+int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches);
+
 /* ---- pointops (libs/pointops) ------------------------------------------------------------------
  * Same argument meaning as the reference's extern "C" launchers
  * (libs/pointops/src/knn_query/knn_query_cuda_kernel.h:9-17, grouping/grouping_cuda_kernel.h,

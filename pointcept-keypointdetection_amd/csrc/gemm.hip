@@ -9,6 +9,7 @@
 // slab order (bitwise reproducible) and finishes with the same epilogue.
 // Reference semantics: include/ptv3_hip.h (ptv3_gemm).
 #include "common.h"
+#include "profile.h"
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -315,6 +316,11 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
              splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps};
   hipStream_t s = (hipStream_t)stream;
   const int bn = (cout % 64 == 0) ? 64 : 32;
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, nbr ? PROF_SUBM_CONV : PROF_LINEAR, 2.0 * m * kvol * cin * cout,
+                              ((double)m * cin * (nbr ? 1 : kvol) + (double)cout * kvol * cin +
+                               (double)m * cout * (1 + (res != nullptr) + (out2 != nullptr))) * esz,
+                              nbr, m * kvol, 2.0 * cin * cout);
   dim3 grid((unsigned)cdiv(m, GM_BM), (unsigned)cdiv(cout, bn), (unsigned)splits);
   if (dtype == PTV3_F32) {
     if (bn == 64) hipLaunchKernelGGL((gemm_kernel<float, 64>), grid, dim3(GM_THREADS), 0, s, a);
@@ -332,6 +338,7 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
     else
       hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
   }
+  prof_end(prof, s);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

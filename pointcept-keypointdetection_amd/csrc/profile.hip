@@ -1,0 +1,87 @@
+// Per-launch HIP-event timing behind ptv3_profile_enable / ptv3_profile_collect (include/ptv3_hip.h).
+#include <vector>
+#include "common.h"
+#include "profile.h"
+#include "../../include/ptv3_hip.h"
+
+namespace ptv3 {
+
+struct ProfRec { int family; double flops, bytes, per_valid; hipEvent_t e0, e1; int slot; };
+static bool g_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static unsigned long long* g_slots = nullptr;
+static int g_nslots = 0;
+constexpr int MAX_SLOTS = 1 << 16;
+
+__global__ void count_valid_kernel(const int32_t* __restrict__ nbr, int64_t n, unsigned long long* out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long c = 0;
+  for (; i < n; i += (int64_t)gridDim.x * blockDim.x) c += nbr[i] >= 0;
+  for (int d = 32; d > 0; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+bool prof_on() { return g_on; }
+
+static hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int prof_begin(hipStream_t s, int family, double flops, double bytes, const int32_t* nbr, int64_t nbr_count,
+               double flops_per_valid) {
+  if (!g_on) return -1;
+  ProfRec r{family, flops, bytes, flops_per_valid, get_event(), get_event(), -1};
+  if (nbr && g_slots && g_nslots < MAX_SLOTS) {
+    r.slot = g_nslots++;
+    hipLaunchKernelGGL(count_valid_kernel, dim3(512), dim3(256), 0, s, nbr, nbr_count, g_slots + r.slot);
+  }
+  (void)hipEventRecord(r.e0, s);
+  g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
+}
+
+void prof_end(int rec, hipStream_t s) {
+  if (rec >= 0) (void)hipEventRecord(g_recs[rec].e1, s);
+}
+
+}  // namespace ptv3
+
+using namespace ptv3;
+
+extern "C" int ptv3_profile_enable(int on) {
+  if (on && !g_slots) {
+    if (hipMalloc(&g_slots, (size_t)MAX_SLOTS * 8) != hipSuccess) { set_error("profile: hipMalloc failed"); return PTV3_ERR_LAUNCH; }
+  }
+  if (on) {
+    (void)hipMemset(g_slots, 0, (size_t)MAX_SLOTS * 8);
+    g_nslots = 0;
+    for (auto& r : g_recs) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
+    g_recs.clear();
+  }
+  g_on = on != 0;
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches) {
+  if (hipDeviceSynchronize() != hipSuccess) { set_error("profile: synchronize failed"); return PTV3_ERR_LAUNCH; }
+  std::vector<unsigned long long> slots(g_nslots > 0 ? g_nslots : 1);
+  if (g_nslots > 0) (void)hipMemcpy(slots.data(), g_slots, (size_t)g_nslots * 8, hipMemcpyDeviceToHost);
+  for (int f = 0; f < PROF_FAMILIES; ++f) { ms[f] = flops[f] = bytes[f] = 0.0; launches[f] = 0; }
+  for (auto& r : g_recs) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.e0, r.e1);
+    ms[r.family] += t;
+    flops[r.family] += r.slot >= 0 ? r.per_valid * (double)slots[r.slot] : r.flops;
+    bytes[r.family] += r.bytes;
+    launches[r.family] += 1;
+    g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+  }
+  g_recs.clear();
+  if (g_slots) (void)hipMemset(g_slots, 0, (size_t)MAX_SLOTS * 8);
+  g_nslots = 0;
+  return PTV3_OK;
+}

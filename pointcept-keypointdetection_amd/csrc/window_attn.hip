@@ -6,6 +6,7 @@
 // of O^T += V^T * P^T, so P never touches LDS.
 // Reference semantics: SerializedAttention.forward, point_transformer_v3m1_base.py:184-216.
 #include "common.h"
+#include "profile.h"
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -240,15 +241,24 @@ extern "C" int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, c
   if (n == 0) return PTV3_OK;
   const int nwin = (int)(n_pad / patch);
   hipStream_t s = (hipStream_t)stream;
+  if (d != 16 && d != 32 && d != 64) {
+    set_error("window_attn: head_dim %d unsupported (16, 32, 64)", d);
+    return PTV3_ERR_UNSUPPORTED;
+  }
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  // algorithmic work: 4*n_pad*patch*c flops; qkv read + out write + the two index maps
+  const int prof = prof_begin(s, PROF_WINDOW_ATTN, 4.0 * n_pad * patch * c,
+                              (double)n_pad * 3 * c * esz + (double)n * c * esz + 4.0 * (n_pad + n), nullptr, 0, 0.0);
+  int rc = PTV3_ERR_UNSUPPORTED;
 #define WA_CASE(T)                                                                                          \
   switch (d) {                                                                                              \
-    case 16: return launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); \
-    case 32: return launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); \
-    case 64: return launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); \
+    case 16: rc = launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); break; \
+    case 32: rc = launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); break; \
+    case 64: rc = launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); break; \
     default: break;                                                                                         \
   }
   if (dtype == PTV3_F32) { WA_CASE(float) } else { WA_CASE(__bf16) }
 #undef WA_CASE
-  set_error("window_attn: head_dim %d unsupported (16, 32, 64)", d);
-  return PTV3_ERR_UNSUPPORTED;
+  prof_end(prof, s);
+  return rc;
 }

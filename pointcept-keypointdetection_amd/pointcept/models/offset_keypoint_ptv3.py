@@ -34,11 +34,14 @@ class OffsetKeypointPTv3(nn.Module):
 
     def forward(self, data_dict):
         _no_training(self)
-        point_output = self.backbone(data_dict)
-        feat = point_output.feat
-        scale, shift = self.head[1].folded()
-        hidden = self.head[0](feat, bn_scale=scale, bn_shift=shift, act=ops.ACT_RELU)
-        pred_flat = self.head[3](hidden).float()
+        point_output = self.backbone(data_dict, _head=self.head)
+        if "_head_out" in point_output.keys():   # head ran inside the native executor
+            pred_flat = point_output.pop("_head_out")
+        else:
+            feat = point_output.feat
+            scale, shift = self.head[1].folded()
+            hidden = self.head[0](feat, bn_scale=scale, bn_shift=shift, act=ops.ACT_RELU)
+            pred_flat = self.head[3](hidden).float()
         pred = pred_flat.view(-1, self.num_keypoints, 4)
 
         result_dict = {}

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from ptv3_hip import ops
+from ptv3_hip import engine as _engine
 from pointcept.models.builder import MODELS
 from pointcept.models.utils.misc import offset2bincount  # noqa: F401  (reference import surface)
 from pointcept.models.utils.structure import Point
@@ -447,6 +448,9 @@ class PointTransformerV3(PointModule):
         self.shuffle_orders = shuffle_orders
         # None: follow torch autocast (bf16) else fp32; or force torch.float32 / torch.bfloat16
         self.compute_dtype = None
+        # True: one ptv3_forward call per forward (native executor) whenever the tree is the standard eval
+        # configuration and no forward hooks are attached; False: module-by-module (same kernels, same results)
+        self.use_engine = True
 
         assert self.num_stages == len(stride) + 1
         assert self.num_stages == len(enc_depths)
@@ -521,7 +525,7 @@ class PointTransformerV3(PointModule):
             return dt
         return torch.float32
 
-    def forward(self, data_dict):
+    def forward(self, data_dict, _head=None):
         _no_training(self)
         with torch.no_grad():
             point = Point(data_dict)
@@ -530,6 +534,12 @@ class PointTransformerV3(PointModule):
             if feat.dtype not in (torch.float32, torch.bfloat16):
                 feat = feat.float()
             point.feat = ops.cast(feat.contiguous(), dtype)
+            if self.use_engine and _engine.eligible(self, _head):
+                point._ensure_grid_coord()
+                point, head_out = _engine.forward(self, point, dtype, _head)
+                if _head is not None:
+                    point["_head_out"] = head_out
+                return point
             point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
             point.sparsify()
             point = self.embedding(point)

@@ -1,0 +1,252 @@
+"""Python side of ptv3_forward (include/ptv3_hip.h): packs a PT-v3m1 module tree into the flat
+parameter table + model description the native executor walks, and runs one forward with it."""
+import ctypes
+from ctypes import c_float, c_int32, c_int64, c_void_p, POINTER
+
+import torch
+
+from .lib import lib, PTV3_F32, PTV3_BF16, ORDER_IDS
+from . import ops
+
+
+class ModelDesc(ctypes.Structure):
+    _fields_ = [("dtype", c_int32), ("in_channels", c_int32), ("num_stages", c_int32), ("num_orders", c_int32),
+                ("enc_depths", c_int32 * 8), ("enc_channels", c_int32 * 8), ("enc_heads", c_int32 * 8),
+                ("enc_patch", c_int32 * 8), ("dec_depths", c_int32 * 8), ("dec_channels", c_int32 * 8),
+                ("dec_heads", c_int32 * 8), ("dec_patch", c_int32 * 8), ("stride", c_int32 * 8),
+                ("enc_mode", c_int32), ("enable_flash", c_int32), ("head_hidden", c_int32), ("head_out", c_int32),
+                ("mlp_ratio", c_float), ("ln_eps", c_float), ("qk_scale", c_float)]
+
+
+class ForwardIO(ctypes.Structure):
+    _fields_ = [("grid_coord", c_void_p), ("coord_is_i64", c_int32), ("feat", c_void_p), ("batch", c_void_p),
+                ("offset", c_void_p), ("offset_host", POINTER(c_int64)), ("b", c_int32), ("n", c_int64),
+                ("depth", c_int32), ("order_ids_host", POINTER(c_int32)), ("pool_perm_host", POINTER(c_int32)),
+                ("code", c_void_p), ("order", c_void_p), ("inverse", c_void_p), ("out_feat", c_void_p),
+                ("out_head", c_void_p), ("stage_points_host", POINTER(c_int64))]
+
+
+def declare(dll):
+    dll.ptv3_forward_workspace_bytes.restype = ctypes.c_size_t
+    dll.ptv3_forward_workspace_bytes.argtypes = [POINTER(ModelDesc), c_int64, ctypes.c_int]
+    dll.ptv3_forward.restype = ctypes.c_int
+    dll.ptv3_forward.argtypes = [POINTER(ModelDesc), POINTER(c_void_p), ctypes.c_int, POINTER(ForwardIO), c_void_p,
+                                 ctypes.c_size_t, c_void_p]
+
+
+def _bn(bn):
+    scale = bn.weight.detach().float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+    shift = bn.bias.detach().float() - bn.running_mean.float() * scale
+    return [scale.contiguous(), shift.contiguous()]
+
+
+def _f32(p):
+    return p.detach().float().contiguous()
+
+
+class Packed:
+    """Flat parameter table of one (backbone, head, dtype); rebuilt when any parameter version changes."""
+
+    def __init__(self, backbone, head, dtype):
+        self.backbone, self.head, self.dtype = backbone, head, dtype
+        self.sources = [t for t in list(backbone.parameters()) + list(backbone.buffers())]
+        if head is not None:
+            self.sources += list(head.parameters()) + list(head.buffers())
+        self.versions = None
+        self.tensors = None
+
+    def fresh(self):
+        v = [(t.data_ptr(), t._version) for t in self.sources]
+        if v != self.versions:
+            with torch.no_grad():
+                self.tensors = self._pack()
+            self.table = (c_void_p * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
+            self.versions = v
+        return self
+
+    def _mat(self, w, cin_pad=None):
+        w = w.detach()
+        if cin_pad is not None and w.shape[-1] != cin_pad:
+            w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[-1]))
+        return w.reshape(w.shape[0], -1).to(self.dtype).contiguous()
+
+    def _block(self, blk):
+        cpe = blk.cpe
+        out = [self._mat(cpe[0].weight), _f32(cpe[0].bias), self._mat(cpe[1].weight), _f32(cpe[1].bias),
+               _f32(cpe[2].weight), _f32(cpe[2].bias), _f32(blk.norm1[0].weight), _f32(blk.norm1[0].bias),
+               self._mat(blk.attn.qkv.weight), _f32(blk.attn.qkv.bias), self._mat(blk.attn.proj.weight),
+               _f32(blk.attn.proj.bias), _f32(blk.norm2[0].weight), _f32(blk.norm2[0].bias)]
+        mlp = blk.mlp[0]
+        out += [self._mat(mlp.fc1.weight), _f32(mlp.fc1.bias), self._mat(mlp.fc2.weight), _f32(mlp.fc2.bias)]
+        return out
+
+    def _pack(self):
+        bb = self.backbone
+        gran = ops.k_granule(self.dtype)
+        stem = bb.embedding.stem
+        self.cin_pad = (bb.embedding.in_channels + gran - 1) // gran * gran
+        t = [self._mat(stem.conv.weight, self.cin_pad)] + _bn(stem.norm)
+        for s in range(bb.num_stages):
+            enc = getattr(bb.enc, f"enc{s}")
+            if s > 0:
+                t += [self._mat(enc.down.proj.weight), _f32(enc.down.proj.bias)] + _bn(enc.down.norm[0])
+            i = 0
+            while hasattr(enc, f"block{i}"):
+                t += self._block(getattr(enc, f"block{i}"))
+                i += 1
+        if not bb.enc_mode:
+            for s in reversed(range(bb.num_stages - 1)):
+                dec = getattr(bb.dec, f"dec{s}")
+                up = dec.up
+                t += [self._mat(up.proj[0].weight), _f32(up.proj[0].bias)] + _bn(up.proj[1])
+                t += [self._mat(up.proj_skip[0].weight), _f32(up.proj_skip[0].bias)] + _bn(up.proj_skip[1])
+                i = 0
+                while hasattr(dec, f"block{i}"):
+                    t += self._block(getattr(dec, f"block{i}"))
+                    i += 1
+        if self.head is not None:
+            h = self.head
+            t += [self._mat(h[0].weight), _f32(h[0].bias)] + _bn(h[1]) + [self._mat(h[3].weight), _f32(h[3].bias)]
+        return t
+
+
+def eligible(backbone, head=None):
+    """True when the module tree is the standard eval-mode PT-v3m1 the native executor implements."""
+    from pointcept.models.utils.hip_layers import Linear, LayerNorm, BatchNorm1d
+    import torch.nn as nn
+    if backbone.training or backbone.enc_mode:
+        return False
+    cached = backbone.__dict__.get("_engine_static_ok")
+    if cached is None:
+        ok = True
+        for m in backbone.modules():
+            n = type(m).__name__
+            if n == "Block":
+                ok &= m.pre_norm and isinstance(m.cpe[2], LayerNorm) and isinstance(m.norm1[0], LayerNorm) \
+                    and isinstance(m.norm2[0], LayerNorm) and isinstance(m.mlp[0].act, nn.GELU) \
+                    and not m.attn.enable_rpe
+            elif n == "SerializedPooling":
+                ok &= m.norm is not None and isinstance(m.norm[0], BatchNorm1d) and m.act is not None \
+                    and isinstance(m.act[0], nn.GELU) and m.shuffle_orders
+            elif n == "SerializedUnpooling":
+                ok &= len(m.proj) == 3 and len(m.proj_skip) == 3 and isinstance(m.proj[1], BatchNorm1d) \
+                    and isinstance(m.proj[2], nn.GELU)
+            elif n == "Embedding":
+                ok &= isinstance(m.stem._modules.get("norm"), BatchNorm1d) and isinstance(m.stem._modules.get("act"), nn.GELU)
+        if head is not None:
+            ok &= (len(head) == 4 and isinstance(head[0], Linear) and isinstance(head[1], BatchNorm1d)
+                   and isinstance(head[2], nn.ReLU) and isinstance(head[3], Linear))
+        backbone.__dict__["_engine_static_ok"] = cached = bool(ok)
+        backbone.__dict__["_engine_modules"] = list(backbone.modules()) + (list(head.modules()) if head is not None else [])
+    if not cached:
+        return False
+    # forward hooks (debug taps, profilers) need the module-by-module path
+    for m in backbone.__dict__["_engine_modules"]:
+        if m._forward_hooks or m._forward_pre_hooks:
+            return False
+    return True
+
+
+def _desc(bb, head, dtype, cin_pad):
+    d = ModelDesc()
+    d.dtype = PTV3_F32 if dtype == torch.float32 else PTV3_BF16
+    d.in_channels = cin_pad
+    d.num_stages = bb.num_stages
+    d.num_orders = len(bb.order)
+    blk0 = bb.enc.enc0.block0
+    for s in range(bb.num_stages):
+        enc = getattr(bb.enc, f"enc{s}")
+        depth = sum(1 for k in enc._modules if k.startswith("block"))
+        b = enc.block0
+        d.enc_depths[s], d.enc_channels[s], d.enc_heads[s] = depth, b.channels, b.attn.num_heads
+        d.enc_patch[s] = b.attn.patch_size if b.attn.enable_flash else b.attn.patch_size_max
+        if s > 0:
+            d.stride[s - 1] = enc.down.stride
+    for s in range(bb.num_stages - 1):
+        dec = getattr(bb.dec, f"dec{s}")
+        depth = sum(1 for k in dec._modules if k.startswith("block"))
+        b = dec.block0
+        d.dec_depths[s], d.dec_channels[s], d.dec_heads[s] = depth, b.channels, b.attn.num_heads
+        d.dec_patch[s] = b.attn.patch_size if b.attn.enable_flash else b.attn.patch_size_max
+    d.enc_mode = 0
+    d.enable_flash = int(blk0.attn.enable_flash)
+    d.mlp_ratio = blk0.mlp[0].fc1.out_features / blk0.channels
+    d.ln_eps = blk0.norm1[0].eps
+    default_scale = (blk0.channels // blk0.attn.num_heads) ** -0.5
+    d.qk_scale = 0.0 if abs(blk0.attn.scale - default_scale) < 1e-12 else blk0.attn.scale
+    if head is not None:
+        d.head_hidden, d.head_out = head[0].out_features, head[3].out_features
+    return d
+
+
+def forward(backbone, point, dtype, head=None):
+    """Runs the native executor.  `point` is a Point with feat (already `dtype`), grid_coord, batch, offset.
+    Fills the Point like the module path does and returns (point, head_out or None)."""
+    dll = lib.load()
+    if not hasattr(dll, "_engine_declared"):
+        declare(dll)
+        dll._engine_declared = True
+    cache = backbone.__dict__.setdefault("_engine_packed", {})
+    key = (dtype, id(head))
+    if key not in cache:
+        cache[key] = Packed(backbone, head, dtype)
+    pk = cache[key].fresh()
+    desc = _desc(backbone, head, dtype, pk.cin_pad)
+
+    k = len(backbone.order)
+    S = backbone.num_stages
+    # the reference's CPU-RNG draws, in its order: serialization (structure.py:101-105), then one per pooling
+    orders = list(backbone.order)
+    if backbone.shuffle_orders:
+        orders = [orders[p] for p in torch.randperm(k).tolist()]
+    perms = []
+    for _ in range(S - 1):
+        perms += torch.randperm(k).tolist()
+    order_ids = (c_int32 * k)(*[ORDER_IDS[o] for o in orders])
+    perm_arr = (c_int32 * max(1, len(perms)))(*perms)
+
+    feat = point.feat
+    n = feat.shape[0]
+    if feat.shape[1] != pk.cin_pad:
+        feat = torch.nn.functional.pad(feat, (0, pk.cin_pad - feat.shape[1])).contiguous()
+    gc = point.grid_coord
+    if gc.dtype not in (torch.int32, torch.int64):
+        gc = gc.long()
+    gc = gc.contiguous()
+    batch = point.batch.long().contiguous()
+    offset = point.offset.long().contiguous()
+    off_host = point.offset_host()
+    nb = len(off_host)
+    depth = int(max(point.grid_max_host()) + 1).bit_length()
+    assert depth * 3 + nb.bit_length() <= 63 and depth <= 16
+    dev = feat.device
+    code = torch.empty((k, n), dtype=torch.int64, device=dev)
+    order = torch.empty_like(code)
+    inverse = torch.empty_like(code)
+    out_feat = torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev)
+    out_head = torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None
+    ws_bytes = dll.ptv3_forward_workspace_bytes(ctypes.byref(desc), n, nb)
+    arena = backbone.__dict__.get("_engine_arena")
+    if arena is None or arena.numel() < ws_bytes or arena.device != dev:
+        arena = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        backbone.__dict__["_engine_arena"] = arena
+    stage_pts = (c_int64 * 8)()
+    io = ForwardIO()
+    io.grid_coord, io.coord_is_i64 = gc.data_ptr(), int(gc.dtype == torch.int64)
+    io.feat, io.batch, io.offset = feat.data_ptr(), batch.data_ptr(), offset.data_ptr()
+    off_arr = (c_int64 * nb)(*off_host)
+    io.offset_host, io.b, io.n, io.depth = off_arr, nb, n, depth
+    io.order_ids_host, io.pool_perm_host = order_ids, perm_arr
+    io.code, io.order, io.inverse = code.data_ptr(), order.data_ptr(), inverse.data_ptr()
+    io.out_feat = out_feat.data_ptr()
+    io.out_head = out_head.data_ptr() if out_head is not None else None
+    io.stage_points_host = stage_pts
+    rc = dll.ptv3_forward(ctypes.byref(desc), pk.table, len(pk.tensors), ctypes.byref(io), arena.data_ptr(),
+                          arena.numel(), ops._stream())
+    lib.check(rc, "ptv3_forward")
+    point["order"] = list(backbone.order)
+    point["serialized_depth"] = depth
+    point["serialized_code"], point["serialized_order"], point["serialized_inverse"] = code, order, inverse
+    point["feat"] = out_feat
+    point["_stage_points"] = [int(stage_pts[i]) for i in range(S)]
+    return point, out_head

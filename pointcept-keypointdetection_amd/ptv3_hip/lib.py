@@ -38,6 +38,10 @@ SIGNATURES = {
     "ptv3_pool_segments": (c_int, [P, P, c_int64, c_int, P, P, P, P, P, P, c_size_t, P]),
     "ptv3_pool_reduce": (c_int, [P, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, P, P, c_int, P, P, P,
                                  P, P, c_int, P]),
+    "ptv3_forward_workspace_bytes": (c_size_t, [P, c_int64, c_int]),
+    "ptv3_forward": (c_int, [P, P, c_int, P, P, c_size_t, P]),
+    "ptv3_profile_enable": (c_int, [c_int]),
+    "ptv3_profile_collect": (c_int, [P, P, P, P]),
     "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "ptv3_grouping_forward": (c_int, [c_int, c_int, c_int, P, P, P, P]),
     "ptv3_grouping_backward": (c_int, [c_int, c_int, c_int, P, P, P, P]),

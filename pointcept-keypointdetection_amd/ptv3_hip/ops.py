@@ -11,29 +11,6 @@ from .lib import lib, PTV3_F32, PTV3_BF16, ACT_NONE, ACT_GELU, ACT_RELU, ORDER_I
 
 _DT = {torch.float32: PTV3_F32, torch.bfloat16: PTV3_BF16}
 
-# Optional per-launch timing for bench.py's roofline section: when PROFILE is a list, the matrix-core ops
-# append (kernel family, start event, end event, work dict) around their launch (events on the launch stream).
-PROFILE = None
-
-
-class _timed:
-    def __init__(self, family, work):
-        self.family, self.work = family, work
-
-    def __enter__(self):
-        if PROFILE is not None:
-            self.e0 = torch.cuda.Event(enable_timing=True)
-            self.e1 = torch.cuda.Event(enable_timing=True)
-            self.e0.record()
-        return self
-
-    def __exit__(self, *exc):
-        if PROFILE is not None:
-            self.e1.record()
-            PROFILE.append((self.family, self.e0, self.e1, self.work))
-        return False
-
-
 _raw_stream = torch._C._cuda_getCurrentRawStream if hasattr(torch._C, "_cuda_getCurrentRawStream") else None
 
 
@@ -144,12 +121,9 @@ def window_attention(qkv, win_order, win_inverse, heads, patch, scale, rpe_bias=
     if rpe_bias is not None and rpe_bias.numel() != (n_pad // patch) * heads * patch * patch:
         raise RuntimeError("window_attention: rpe_bias must be (n_pad/patch, heads, patch, patch)")
     out = torch.empty((n, c), dtype=qkv.dtype, device=qkv.device)
-    es = qkv.element_size()
-    with _timed("window_attn", dict(flops=4.0 * n_pad * patch * c, exps=float(n_pad) * patch * heads,
-                                    bytes=n_pad * 3 * c * es + n * c * es + 4 * (n_pad + n))):
-        lib.check(lib.ptv3_window_attn_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(out), n, n_pad, c,
-                                           int(heads), int(patch), float(scale), _p(rpe_bias), _dt(qkv),
-                                           _stream()), "ptv3_window_attn_fwd")
+    lib.check(lib.ptv3_window_attn_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(out), n, n_pad, c, int(heads),
+                                       int(patch), float(scale), _p(rpe_bias), _dt(qkv), _stream()),
+              "ptv3_window_attn_fwd")
     return out
 
 
@@ -204,16 +178,12 @@ def gemm(x, w, bias=None, nbr=None, kvol=1, row_order=None, bn_scale=None, bn_sh
         raise RuntimeError("gemm: row_order length != m")
     out = torch.empty((m, cout), dtype=x.dtype, device=x.device)
     out2 = torch.empty_like(out) if dual else None
-    es = x.element_size()
-    work = dict(flops=2.0 * m * kvol * cin * cout, nbr=nbr, cin=cin, cout=cout,
-                bytes=(m * kvol * cin + cout * kvol * cin + m * cout * (1 + (res is not None) + dual)) * es)
     dt = _dt(x)
     ws_bytes = lib.ptv3_gemm_workspace_bytes(m, cin, cout, int(kvol), dt)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
-    with _timed("subm_conv" if nbr is not None else "linear", work):
-        lib.check(lib.ptv3_gemm(_p(x), _p(w), _p(out), m, cin, cout, int(kvol), _p(nbr), _p(row_order), _p(bias),
-                                _p(bn_scale), _p(bn_shift), int(act), _p(res), _p(res_index), _p(out2), dt,
-                                _p(ws), ws_bytes, _stream()), "ptv3_gemm")
+    lib.check(lib.ptv3_gemm(_p(x), _p(w), _p(out), m, cin, cout, int(kvol), _p(nbr), _p(row_order), _p(bias),
+                            _p(bn_scale), _p(bn_shift), int(act), _p(res), _p(res_index), _p(out2), dt, _p(ws),
+                            ws_bytes, _stream()), "ptv3_gemm")
     return (out, out2) if dual else out
 
 
@@ -319,3 +289,22 @@ def knn_query(nsample, xyz, offset, new_xyz, new_offset):
     lib.check(lib.ptv3_knn_query(m, int(nsample), _p(xyz), _p(new_xyz), _p(offset), _p(new_offset),
                                  offset.shape[0], _p(idx), _p(dist2), _stream()), "ptv3_knn_query")
     return idx, dist2
+
+
+# ---------------------------------------------------------------------------------------------
+# measurement
+# ---------------------------------------------------------------------------------------------
+FAMILIES = ("linear", "subm_conv", "window_attn")
+
+
+def profile_enable(on=True):
+    lib.check(lib.ptv3_profile_enable(int(on)), "ptv3_profile_enable")
+
+
+def profile_collect():
+    """{family: dict(ms, flops, bytes, launches)} of the device time bracketed by HIP events since enable."""
+    n = len(FAMILIES)
+    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    la = (ctypes.c_int64 * n)()
+    lib.check(lib.ptv3_profile_collect(ms, fl, by, la), "ptv3_profile_collect")
+    return {FAMILIES[i]: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i])) for i in range(n)}

@@ -373,6 +373,33 @@ def test_tiny_model_golden(dev, golden_dir):
     assert abs(out["loss"].item() - float(g["loss"])) < FP32_TOL
 
 
+def test_native_executor_matches_module_path_and_golden(dev, golden_dir):
+    """ptv3_forward (one C-ABI call) against the module-by-module path: bitwise equal in fp32 (same kernels,
+    same order), and against the reference's own output."""
+    g = _g(golden_dir, "ptv3_tiny.npz")
+    model = _build(TINY_CFG, hidden_dim=32)
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
+    model = model.to(dev).eval()
+    data = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    outs = {}
+    for use in (True, False):
+        model.backbone.use_engine = use
+        torch.manual_seed(int(g["shuffle_seed"]))
+        with torch.no_grad():
+            outs[use] = model(data)
+    assert torch.equal(outs[True]["pred"], outs[False]["pred"])
+    assert np.abs(outs[True]["pred"].cpu().numpy() - g["pred"]).max() < FP32_TOL
+    assert abs(outs[True]["loss"].item() - float(g["loss"])) < FP32_TOL
+    # backbone-only call (DefaultSegmentorV2 route): Point with features in input order + serialization keys
+    model.backbone.use_engine = True
+    torch.manual_seed(int(g["shuffle_seed"]))
+    with torch.no_grad():
+        pt = model.backbone(data)
+    assert np.abs(pt.feat.cpu().numpy() - g["tap_dec0"]).max() < FP32_TOL
+    assert np.array_equal(pt.serialized_code.cpu().numpy(), g["tap_serialized_code"])
+    assert np.array_equal(pt.serialized_order.cpu().numpy(), g["tap_serialized_order"])
+
+
 @pytest.mark.parametrize("sizes,kind,extent", [([12000, 9000], "surface", 128), ([15000], "lidar", 1024)])
 def test_fork_config_vs_oracle(dev, sizes, kind, extent):
     """configs/my_dataset/offset_keypoint_ptv3.py shape (46M parameters) - HIP model against the oracle
