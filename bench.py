@@ -26,6 +26,20 @@ import torch.distributed as dist  # noqa: E402
 PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 
 
+def rank_scene_seeds(rank, scenes_per_rank):
+    """Scene shard of one rank: disjoint seeds, `scenes_per_rank` scenes each (weak scaling, no exchange)."""
+    return [1000 + rank * scenes_per_rank + i for i in range(scenes_per_rank)]
+
+
+def reduce_over_ranks(value, device, op):
+    """MAX of the timed region / SUM of the points over the job (the only collectives of the bench)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,9 +132,8 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.backbone.compute_dtype = dtype
     # every rank owns its own scene(s): shard = scene, no exchange on the data path
-    batch = S.make_batch([args.points] * args.scenes, in_channels=4, extent=None, seed=1000 + rank,
-                         kind=args.kind, device="cpu")
-    batch = {k: v.to(device) for k, v in batch.items()}
+    scenes = [S.make_scene(args.points, 4, None, seed, args.kind) for seed in rank_scene_seeds(rank, args.scenes)]
+    batch = {k: v.to(device) for k, v in S.collate(scenes).items()}
     n_points = args.points * args.scenes
 
     def step():
@@ -144,10 +157,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_over_ranks(elapsed, device, dist.ReduceOp.MAX)
+    total_points = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
 
     # ---- per-kernel-family device time from the events recorded during the timed steps
     roofline = None
@@ -169,7 +180,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         line = {
             "metric": "Mpoints/sec PTv3 fwd @100k pts/scene, 1024-pt window; keypoint offset L2 vs ref",
-            "value": round(n_points * world * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
+            "value": round(total_points * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
