@@ -160,9 +160,9 @@ int ptv3_pool_reduce(const void* feat, const float* coord, const int64_t* grid_c
  * are identical to composing the per-op entry points.
  * params: flat table of device pointers in module order -
  *   stem conv w, stem BN scale, shift;
- *   per encoder stage s: [s>0: down.proj w, b, BN scale, shift] then per block the 18 pointers
- *     cpe conv w, b, cpe linear w, b, cpe LN g, b, norm1 g, b, qkv w, b, proj w, b, norm2 g, b,
- *     fc1 w, b, fc2 w, b;
+ *   per encoder stage s: [s>0: down.proj w, b, BN scale, shift] then per block the 16 pointers
+ *     cpe conv w, b (with the cpe Linear folded in: W'_d = W_lin W_d, b' = W_lin b_conv + b_lin),
+ *     cpe LN g, b, norm1 g, b, qkv w, b, proj w, b, norm2 g, b, fc1 w, b, fc2 w, b;
  *   per decoder stage s = S-2..0: up.proj w, b, BN scale, shift, up.proj_skip w, b, BN scale, shift, blocks;
  *   head (if head_out > 0): linear0 w, b, BN scale, shift, linear1 w, b.
  *   matrices in `dtype` (conv weights (cout, kvol, cin) with cin padded to the 16-byte granule),

@@ -126,8 +126,7 @@ struct Run {
 
   // Block.forward (:318-338), eval, pre_norm; writes the new features into `L.feat` (same buffer)
   void block(Level& L, int C, int H, int patch, int oi) {
-    const void* conv_w = next(); const float* conv_b = (const float*)next();
-    const void* lin_w = next(); const float* lin_b = (const float*)next();
+    const void* conv_w = next(); const float* conv_b = (const float*)next();  // cpe Linear folded in
     const float* ln0_g = (const float*)next(); const float* ln0_b = (const float*)next();
     const float* n1_g = (const float*)next(); const float* n1_b = (const float*)next();
     const void* qkv_w = next(); const float* qkv_b = (const float*)next();
@@ -143,11 +142,10 @@ struct Run {
     attention_plan(L, patch, oi);
     const size_t mark = A->off;
     const size_t row = (size_t)L.n * es;
-    void* t1 = alloc(row * C); void* t2 = alloc(row * C); void* f1 = alloc(row * C); void* t3 = alloc(row * C);
+    void* t2 = alloc(row * C); void* f1 = alloc(row * C); void* t3 = alloc(row * C);
     void* qkv = alloc(row * 3 * C); void* t4 = alloc(row * C); void* f2 = alloc(row * C); void* t5 = alloc(row * C);
     void* t6 = alloc(row * hidden);
-    gemm(L.conv_feat, conv_w, t1, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-    gemm(t1, lin_w, t2, L.n, C, C, 1, nullptr, nullptr, lin_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+    gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, s));
     gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     const float scale = d->qk_scale > 0.f ? d->qk_scale : 1.0f / sqrtf((float)(C / H));

@@ -270,10 +270,10 @@ static int choose_splits(int64_t m, int cin, int cout, int kvol, int dtype, int*
   const int bn = (cout % 64 == 0) ? 64 : 32;
   const int64_t base = cdiv(m, GM_BM) * cdiv(cout, bn);
   int splits = 1;
-  if (nsteps >= 8 && base < 1024) {
-    int64_t want = 2048 / base;
+  if (nsteps >= 16 && base < 512) {
+    int64_t want = 1536 / base;
     if (want > nsteps / 4) want = nsteps / 4;
-    if (want > 1) splits = (int)want;
+    if (want >= 4) splits = (int)want;  // a 2-3 way split does not pay for its reduce launch
   }
   int sps = (nsteps + splits - 1) / splits;
   splits = (nsteps + sps - 1) / sps;

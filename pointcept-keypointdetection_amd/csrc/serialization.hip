@@ -92,33 +92,29 @@ radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift, uint3
   hist[((int64_t)row * 256 + threadIdx.x) * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-// one block per row: exclusive scan of 256*nblk counters
-__global__ void __launch_bounds__(1024) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry_s;
-  uint32_t* h = hist + (int64_t)blockIdx.x * 256 * nblk;
-  const int total = 256 * nblk;
+// one 256-thread block per row: exclusive scan of the digit-major (256 x nblk) counters.
+// thread d owns digit d: sums its nblk block counters, the 256 digit totals are scanned across the block,
+// then the thread rewrites its counters as running bases.
+__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk) {
+  __shared__ uint32_t wsum[4];
+  uint32_t* h = hist + ((int64_t)blockIdx.x * 256 + threadIdx.x) * nblk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < total; base += 1024) {
-    int i = base + threadIdx.x;
-    uint32_t v = i < total ? h[i] : 0u;
-    uint32_t x = v;
+  uint32_t total = 0;
+  for (int b = 0; b < nblk; ++b) total += h[b];
+  uint32_t x = total;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      uint32_t t = __shfl_up(x, d, 64);
-      if (lane >= d) x += t;
-    }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    uint32_t carry = carry_s;
-    if (i < total) h[i] = carry + woff + x - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + x;
-    __syncthreads();
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(x, d, 64);
+    if (lane >= d) x += t;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t base = x - total;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  for (int b = 0; b < nblk; ++b) {
+    uint32_t c = h[b];
+    h[b] = base;
+    base += c;
   }
 }
 
@@ -323,7 +319,7 @@ extern "C" int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_b
     const int shift = 8 * p;
     const bool first = p == 0, last = p == passes - 1;
     hipLaunchKernelGGL(radix_hist_kernel, grid, block, 0, s, kin, n, shift, hist, nblk);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(k), dim3(1024), 0, s, hist, nblk);
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(k), dim3(256), 0, s, hist, nblk);
     uint64_t* kout = kbuf[p & 1];
     uint32_t* vout = vbuf[p & 1];
     if (first && last)

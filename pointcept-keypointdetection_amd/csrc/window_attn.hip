@@ -211,11 +211,243 @@ window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_or
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Resident-window variant: the K and V of the whole (window, head) are staged into LDS ONCE
+// (bf16, K=1024, head_dim 16: 40 KB + 33 KB), then every wave streams its 64 queries over all key
+// tiles with no further barrier.  Softmax rescale is lazy: the cross-lane max exchange and the O / l
+// rescale only run (wave-uniformly) when some row maximum grew by more than 2^8 since the last
+// rescale; exact (softmax is shift invariant), removes two lane exchanges per tile from the
+// dependency chain.  Used whenever the window fits LDS; the tiled kernel above is the fallback.
+// ------------------------------------------------------------------------------------------------
+constexpr float WA_RESCALE_THR = 8.0f;  // log2 units: probabilities stay <= 256 between rescales
+
+__device__ __forceinline__ float lanes_max_groups(float x) {
+  // all-reduce max over the 4 lane groups g = lane >> 4 that share one query (lanes l, l^16, l^32, l^48);
+  // only on the rare rescale path, so the LDS-crossbar shuffle is fine here
+  x = fmaxf(x, __shfl_xor(x, 16, 64));
+  return fmaxf(x, __shfl_xor(x, 32, 64));
+}
+__device__ __forceinline__ float lanes_sum_groups(float x) {
+  x += __shfl_xor(x, 16, 64);
+  return x + __shfl_xor(x, 32, 64);
+}
+
+template <typename T> struct WaFull {
+  static constexpr int VPAD = sizeof(T) == 2 ? 8 : 4;  // V^T row padding (elements): conflict-free fragment reads
+};
+
+template <typename T, int ND>
+__global__ void __launch_bounds__(512)
+window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
+                        const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
+                        int Kpad, int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe) {
+  typedef typename Vec4<T>::type V4;
+  constexpr int D = 16 * ND;
+  constexpr int QT = WaCfg<T, ND>::QT;
+  constexpr int KS = D + 4;
+  const int VS = Kpad + WaFull<T>::VPAD;
+  const int nthreads = blockDim.x;
+  const int QB = (nthreads >> 6) * QT * 16;  // queries per workgroup
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sK = reinterpret_cast<T*>(smem);                         // [Kpad][KS]
+  T* sV = sK + (size_t)Kpad * KS;                             // [D][VS]
+  int32_t* sOrd = reinterpret_cast<int32_t*>(sV + (size_t)D * VS);  // [Kpad]
+
+  const unsigned nwg = (unsigned)nwin * H * qsplit;
+  const unsigned logical = xcd_remap(blockIdx.x, nwg);
+  const int w = logical / (H * qsplit);
+  const int rem = logical % (H * qsplit);
+  const int h = rem / qsplit;
+  const int qs = rem % qsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t wbase = (int64_t)w * K;
+  const int C3 = 3 * C;
+
+  for (int i = tid; i < Kpad; i += nthreads) sOrd[i] = i < K ? win_order[wbase + i] : -1;
+  __syncthreads();
+
+  // ---- stage the whole window: K row-major, V transposed
+  constexpr int CH = D / 4;
+  const int total = Kpad * CH;
+  for (int e0 = tid; e0 < total; e0 += 4 * nthreads) {
+    V4 rk[4], rv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * nthreads;
+      rk[u] = zero4<T>();
+      rv[u] = zero4<T>();
+      if (e < total) {
+        const int row = sOrd[e / CH];
+        if (row >= 0) {
+          const T* base = qkv + (int64_t)row * C3 + h * D + 4 * (e % CH);
+          rk[u] = *reinterpret_cast<const V4*>(base + C);
+          rv[u] = *reinterpret_cast<const V4*>(base + 2 * C);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * nthreads;
+      if (e < total) {
+        const int kk = e / CH, ch = e % CH;
+        *reinterpret_cast<V4*>(sK + (size_t)kk * KS + 4 * ch) = rk[u];
+        const T* pv = reinterpret_cast<const T*>(&rv[u]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sV[(size_t)(4 * ch + q) * VS + kk] = pv[q];
+      }
+    }
+  }
+
+  // ---- Q fragments of this wave (global loads overlap the staging above)
+  V4 qf[QT][ND];
+  int qidx[QT];
+  bool any_q = false;
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    qidx[t] = qs * QB + (wave * QT + t) * 16 + li;
+    const bool qv = qidx[t] < K;
+    any_q |= qv;
+    const int row = qv ? sOrd[qidx[t]] : 0;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) {
+      V4 raw = zero4<T>();
+      if (qv) raw = *reinterpret_cast<const V4*>(qkv + (int64_t)row * C3 + h * D + 16 * c + 4 * g);
+      float f[4];
+      unpack4<T>(raw, f);
+      qf[t][c] = pack4<T>(f[0] * scale_log2e, f[1] * scale_log2e, f[2] * scale_log2e, f[3] * scale_log2e);
+    }
+  }
+  __syncthreads();
+  if (!__any(any_q)) return;  // whole wave past the window end: nothing left to synchronise with
+
+  f32x4 o[QT][ND];
+  float m[QT], l[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    m[t] = -INFINITY;
+    l[t] = 0.f;
+#pragma unroll
+    for (int c = 0; c < ND; ++c) o[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int ntiles = Kpad / WA_KT;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int key0 = tile * WA_KT;
+    V4 kf[4][ND], vf[ND][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int c = 0; c < ND; ++c) {
+        kf[kt][c] = *reinterpret_cast<const V4*>(sK + (size_t)(key0 + 16 * kt + li) * KS + 16 * c + 4 * g);
+        vf[c][kt] = *reinterpret_cast<const V4*>(sV + (size_t)(16 * c + li) * VS + key0 + 16 * kt + 4 * g);
+      }
+    const bool tail = key0 + WA_KT > K;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      f32x4 s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < ND; ++c) acc = mma16<T>(kf[kt][c], qf[t][c], acc);
+        s[kt] = acc;
+      }
+      if (rpe != nullptr && qidx[t] < K) {
+        const float* rb = rpe + (((int64_t)w * H + h) * K + qidx[t]) * K;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int key = key0 + 16 * kt + 4 * g + r;
+            if (key < K) s[kt][r] += rb[key] * 1.44269504088896340736f;
+          }
+      }
+      if (tail) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + 16 * kt + 4 * g + r >= K) s[kt][r] = -INFINITY;
+      }
+      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
+                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])),
+                           fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+      if (__any(mx > m[t] + WA_RESCALE_THR)) {  // wave-uniform; rare after the first tiles
+        const float mn = fmaxf(m[t], lanes_max_groups(mx));
+        const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
+        m[t] = mn;
+        l[t] *= alpha;
+#pragma unroll
+        for (int c = 0; c < ND; ++c) o[t][c] *= alpha;
+      }
+      const float mt = m[t];
+      float ps = 0.f;
+      V4 pf[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mt);
+        float p1 = __builtin_amdgcn_exp2f(s[kt][1] - mt);
+        float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mt);
+        float p3 = __builtin_amdgcn_exp2f(s[kt][3] - mt);
+        ps += (p0 + p1) + (p2 + p3);
+        pf[kt] = pack4<T>(p0, p1, p2, p3);
+      }
+      l[t] += ps;
+#pragma unroll
+      for (int c = 0; c < ND; ++c)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) o[t][c] = mma16<T>(vf[c][kt], pf[kt], o[t][c]);
+    }
+  }
+
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    const float inv = 1.0f / lanes_sum_groups(l[t]);
+    if (qidx[t] < K) {
+      const int row = sOrd[qidx[t]];
+      if (win_inverse[row] == (int32_t)(wbase + qidx[t])) {
+#pragma unroll
+        for (int c = 0; c < ND; ++c) {
+          V4 v = pack4<T>(o[t][c][0] * inv, o[t][c][1] * inv, o[t][c][2] * inv, o[t][c][3] * inv);
+          *reinterpret_cast<V4*>(out + (int64_t)row * C + h * D + 16 * c + 4 * g) = v;
+        }
+      }
+    }
+  }
+}
+
+
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
                               int K, int nwin, float scale, const float* rpe, hipStream_t s) {
   constexpr int D = 16 * ND;
-  constexpr int QB = WA_WAVES * WaCfg<T, ND>::QT * 16;
+  constexpr int QT = WaCfg<T, ND>::QT;
+  const int Kpad = (K + WA_KT - 1) / WA_KT * WA_KT;
+  const size_t lds_full = ((size_t)Kpad * (D + 4) + (size_t)D * (Kpad + WaFull<T>::VPAD)) * sizeof(T) + (size_t)Kpad * 4;
+  static bool attr_set = false;
+  if (lds_full <= 160 * 1024) {
+    // queries per workgroup: 8 waves (512 queries at head_dim 16) when there are plenty of windows, fewer
+    // waves per workgroup when the grid would otherwise leave CUs idle
+    int waves = 8;
+    while (waves > 4 && (int64_t)nwin * H * ((K + waves * QT * 16 - 1) / (waves * QT * 16)) < 512) waves >>= 1;
+    const int QB = waves * QT * 16;
+    const int qsplit = (K + QB - 1) / QB;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    const unsigned nwg = (unsigned)nwin * H * qsplit;
+    hipLaunchKernelGGL((window_attn_full_kernel<T, ND>), dim3(nwg), dim3(waves * 64), lds_full, s, (const T*)qkv, wo,
+                       wi, (T*)out, C, H, K, Kpad, nwin, qsplit, scale * 1.44269504088896340736f, rpe);
+    PTV3_LAUNCH_CHECK();
+    return PTV3_OK;
+  }
+  constexpr int QB = WA_WAVES * QT * 16;
   const int qsplit = (K + QB - 1) / QB;
   const size_t lds = (size_t)(WA_KT * (D + 4) + D * (WA_KT + 4)) * sizeof(T) + (size_t)K * 4;
   const unsigned nwg = (unsigned)nwin * H * qsplit;

@@ -21,7 +21,7 @@ from ptv3_hip import engine as _engine
 from pointcept.models.builder import MODELS
 from pointcept.models.utils.misc import offset2bincount  # noqa: F401  (reference import surface)
 from pointcept.models.utils.structure import Point
-from pointcept.models.utils.sparse import SubMConv3d
+from pointcept.models.utils.sparse import SubMConv3d, _ParamCache
 from pointcept.models.utils.hip_layers import (Linear, LayerNorm, BatchNorm1d, GELU, DropPath, _no_training)
 from pointcept.models.modules import PointModule, PointSequential
 
@@ -188,7 +188,23 @@ class Block(PointModule):
 
     def _fusable(self):
         return (self.pre_norm and isinstance(self.cpe[2], LayerNorm) and isinstance(self.norm1[0], LayerNorm)
-                and isinstance(self.norm2[0], LayerNorm))
+                and isinstance(self.norm2[0], LayerNorm) and isinstance(self.cpe[0], SubMConv3d)
+                and isinstance(self.cpe[1], Linear))
+
+    def folded_cpe(self, dtype):
+        """xCPE conv followed by its Linear (:277-285) has no nonlinearity in between, so the Linear is folded
+        into the 27 kernel taps once per weight version:  W'_d = W_lin @ W_d,  b' = W_lin @ b_conv + b_lin.
+        Saves one GEMM launch and one (N, C) round trip per block; fp32 reassociation only."""
+        conv, lin = self.cpe[0], self.cpe[1]
+        cache = self.__dict__.setdefault("_fold_cache", _ParamCache())
+
+        def make():
+            wc = conv.weight.detach().float().reshape(conv.out_channels, -1, conv.in_channels)
+            wl = lin.weight.detach().float()
+            w = torch.einsum("oc,ckd->okd", wl, wc).reshape(lin.out_features, -1)
+            b = wl @ conv.bias.detach().float() + lin.bias.detach().float()
+            return w.to(dtype).contiguous(), b.contiguous()
+        return cache.get(("cpe", dtype), [conv.weight, conv.bias, lin.weight, lin.bias], make)
 
     def forward(self, point: Point):
         _no_training(self)
@@ -196,8 +212,10 @@ class Block(PointModule):
             return self._forward_generic(point)
         # ---- fused eval path: 9 launches per block, residual adds and norms folded into epilogues
         shortcut = point.feat
-        sp = self.cpe[0](point.sparse_conv_feat)            # xCPE conv (reads the sparse tensor's features)
-        x = self.cpe[1](sp.features)
+        spt = point.sparse_conv_feat                         # xCPE conv reads the sparse tensor's features
+        wf, bf = self.folded_cpe(spt.features.dtype)
+        x = ops.gemm(spt.features, wf, bias=bf, nbr=spt.neighbors(3, self.cpe[0].indice_key), kvol=27,
+                     row_order=spt.row_order)
         g1, b1 = self.cpe[2].affine_f32()
         g2, b2 = self.norm1[0].affine_f32()
         feat, x = ops.layernorm(x, g1, b1, self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)

@@ -72,7 +72,8 @@ class Packed:
 
     def _block(self, blk):
         cpe = blk.cpe
-        out = [self._mat(cpe[0].weight), _f32(cpe[0].bias), self._mat(cpe[1].weight), _f32(cpe[1].bias),
+        wf, bf = blk.folded_cpe(self.dtype)   # conv with the cpe Linear folded in
+        out = [wf, bf,
                _f32(cpe[2].weight), _f32(cpe[2].bias), _f32(blk.norm1[0].weight), _f32(blk.norm1[0].bias),
                self._mat(blk.attn.qkv.weight), _f32(blk.attn.qkv.bias), self._mat(blk.attn.proj.weight),
                _f32(blk.attn.proj.bias), _f32(blk.norm2[0].weight), _f32(blk.norm2[0].bias)]
