@@ -24,6 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+PEAK_HBM = 8000.0                       # GB/s, same table (6.3 TB/s is the measured achievable copy rate)
 
 
 def rank_scene_seeds(rank, scenes_per_rank):
@@ -167,14 +168,26 @@ def main():
         ops.profile_enable(False)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         d = fam[dom]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK[args.dtype],
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK[args.dtype], 5), "traffic": None,
+        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+        # which roof binds this family: algorithmic intensity against the machine balance of the dtype
+        intensity = d["flops"] / max(d["bytes"], 1.0)
+        hbm_bound = intensity * PEAK_HBM * 1e9 < PEAK[args.dtype] * 1e12
+        roofline = {"kernel": dom,
+                    "bound": "hbm" if hbm_bound else "mfma",
+                    "achieved": round(gbs if hbm_bound else tf, 3),
+                    "peak": PEAK_HBM if hbm_bound else PEAK[args.dtype],
+                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                    "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[args.dtype]), 5),
+                    "traffic": None,
+                    "intensity_flop_per_byte": round(intensity, 1),
                     "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
                     "launches_per_step": d["launches"] // args.steps,
                     "algorithmic_gflop_per_step": round(d["flops"] / args.steps / 1e9, 3),
+                    "algorithmic_mb_per_step": round(d["bytes"] / args.steps / 1e6, 3),
                     "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()},
-                    "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()}}
+                    "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()},
+                    "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()}}
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -69,6 +69,12 @@ int ptv3_window_maps(const int64_t* order, const int64_t* inverse, const int64_t
                      const int64_t* unpad, int64_t n, int64_t n_pad, int32_t* win_order,
                      int32_t* win_inverse, void* stream);
 
+/* pad plan + both maps for all k orders in one launch (no pad / unpad materialised): the executor's form of
+ * the two entry points above.  order / inverse: (k, n); win_order: (k, n_pad); win_inverse: (k, n). */
+int ptv3_window_plan(const int64_t* order, const int64_t* inverse, const int64_t* offset, int b, int k,
+                     int64_t n, int64_t n_pad, int patch, int32_t* win_order, int32_t* win_inverse,
+                     void* stream);
+
 /* ---- window attention ----------------------------------------------------------------------
  * replaces the vanilla branch of SerializedAttention.forward (point_transformer_v3m1_base.py:188-216)
  * = what flash_attn_varlen_qkvpacked_func computes on the reference's CUDA path (:208-214):
@@ -145,13 +151,14 @@ int ptv3_pool_segments(const int64_t* code0, const int64_t* order0, int64_t n, i
  *   feat_out[j]  = act(max_members(feat[.]) * bn_scale + bn_shift)        (n_out, c) dtype
  *   coord_out[j] = mean_members(coord[.])                                  (n_out, 3) fp32
  *   head = first member: grid_out[j] = grid_coord[head] >> pooling_depth (int64), batch_out[j] =
- *   batch[head], code_out[r][j] = code[r][head] >> 3*pooling_depth for r < k. */
+ *   batch[head], code_out[r][j] = code[perm[r]][head] >> 3*pooling_depth for r < k, where perm is the
+ *   order shuffle of :408-412 (row_perm_host, k host ints; NULL = identity). */
 int ptv3_pool_reduce(const void* feat, const float* coord, const int64_t* grid_coord,
                      const int64_t* batch, const int64_t* code, int k, const int64_t* order0,
                      const int32_t* seg_start, int64_t n, int64_t n_out, int c, int pooling_depth,
-                     const float* bn_scale, const float* bn_shift, int act, void* feat_out,
-                     float* coord_out, int64_t* grid_out, int64_t* batch_out, int64_t* code_out,
-                     int dtype, void* stream);
+                     const float* bn_scale, const float* bn_shift, int act, const int* row_perm_host,
+                     void* feat_out, float* coord_out, int64_t* grid_out, int64_t* batch_out,
+                     int64_t* code_out, int dtype, void* stream);
 
 /* ---- whole-model forward ------------------------------------------------------------------------
  * PointTransformerV3.forward (point_transformer_v3m1_base.py:699-714) in eval mode, optionally followed by

@@ -102,26 +102,24 @@ struct Run {
       K = (int)std::min<int64_t>(mn, patch);
     }
     if (K != L.K) {
-      int64_t n_pad = 0, nwin = 0, prev = 0;
+      int64_t n_pad = 0, prev = 0;
       for (int64_t o : L.off_host) {
         int64_t cnt = o - prev;
         n_pad += cnt > K ? (cnt + K - 1) / K * K : cnt;
-        nwin += (cnt + K - 1) / K;
         prev = o;
       }
       L.K = K; L.n_pad = n_pad;
-      L.pad = (int64_t*)alloc((size_t)n_pad * 8);
-      L.unpad = (int64_t*)alloc((size_t)L.n * 8);
-      L.cu = (int32_t*)alloc((size_t)(nwin + 1) * 4);
-      RUN(ptv3_pad_plan(L.offset, (int)L.off_host.size(), L.n, n_pad, K, L.pad, L.unpad, L.cu, s));
-      for (int i = 0; i < 8; ++i) L.wo[i] = L.wi[i] = nullptr;
+      // one launch: pad plan + both window maps of every order (:114-170, :184-185)
+      const int k = d->num_orders;
+      int32_t* wo = (int32_t*)alloc((size_t)k * n_pad * 4);
+      int32_t* wi = (int32_t*)alloc((size_t)k * L.n * 4);
+      RUN(ptv3_window_plan(L.order, L.inverse, L.offset, (int)L.off_host.size(), k, L.n, n_pad, K, wo, wi, s));
+      for (int i = 0; i < 8; ++i) {
+        L.wo[i] = i < k ? wo + (int64_t)i * n_pad : nullptr;
+        L.wi[i] = i < k ? wi + (int64_t)i * L.n : nullptr;
+      }
     }
-    if (!L.wo[oi]) {
-      L.wo[oi] = (int32_t*)alloc((size_t)L.n_pad * 4);
-      L.wi[oi] = (int32_t*)alloc((size_t)L.n * 4);
-      RUN(ptv3_window_maps(L.order + (int64_t)oi * L.n, L.inverse + (int64_t)oi * L.n, L.pad, L.unpad, L.n, L.n_pad,
-                           L.wo[oi], L.wi[oi], s));
-    }
+    (void)oi;
   }
 
   // Block.forward (:318-338), eval, pre_norm; writes the new features into `L.feat` (same buffer)
@@ -227,19 +225,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
       if (!R.ok()) break;
       L.n = L.off_host[io->b - 1]; L.depth = P.depth - pd; L.offset = poff; L.channels = C;
       if (io->stage_points_host) io->stage_points_host[st] = L.n;
-      // permuted source rows for the pooled codes (same draw as :408-412)
-      const int* perm = io->pool_perm_host + (size_t)(st - 1) * k;
-      bool ident = true;
-      for (int r = 0; r < k; ++r) ident = ident && perm[r] == r;
-      const int64_t* code_src = P.code;
-      if (!ident) {
-        int64_t* tmp = (int64_t*)R.alloc((size_t)k * P.n * 8);
-        if (!dry && R.ok())
-          for (int r = 0; r < k; ++r)
-            (void)hipMemcpyAsync(tmp + (int64_t)r * P.n, P.code + (int64_t)perm[r] * P.n, (size_t)P.n * 8,
-                           hipMemcpyDeviceToDevice, s);
-        code_src = tmp;
-      }
+      const int* perm = io->pool_perm_host + (size_t)(st - 1) * k;  // order shuffle of :408-412
       // pooled level tensors (sized by the n_out just read back); the stage's temporaries simply stay
       // allocated below them for the rest of the forward (a few MB)
       L.feat = R.alloc((size_t)L.n * C * es);
@@ -249,8 +235,8 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
       L.order = (int64_t*)R.alloc((size_t)k * L.n * 8);
       L.inverse = (int64_t*)R.alloc((size_t)k * L.n * 8);
       if (!dry && R.ok()) {
-        int r = ptv3_pool_reduce(proj, nullptr, P.grid, P.batch, code_src, k, P.order, seg, P.n, L.n, C, pd, bns, bnt,
-                                 PTV3_ACT_GELU, L.feat, nullptr, g, bt, L.code, d->dtype, s);
+        int r = ptv3_pool_reduce(proj, nullptr, P.grid, P.batch, P.code, k, P.order, seg, P.n, L.n, C, pd, bns, bnt,
+                                 PTV3_ACT_GELU, perm, L.feat, nullptr, g, bt, L.code, d->dtype, s);
         if (r) R.rc = r;
       }
       L.grid = g; L.batch = bt; L.conv_feat = L.feat;

@@ -8,6 +8,7 @@
 // rows against K = 27*C up to 13824) are split over K into fp32 slabs that a second kernel sums in
 // slab order (bitwise reproducible) and finishes with the same epilogue.
 // Reference semantics: include/ptv3_hip.h (ptv3_gemm).
+#include <stdlib.h>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
@@ -111,17 +112,17 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int64_t orow, 
   }
 }
 
-template <typename T, int BN>
+template <typename T, int NT>
 __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
+  constexpr int BN = 16 * NT;  // output channels per workgroup
   typedef Frag<T> F;
   typedef typename F::type FR;
   constexpr int E = F::E;
   constexpr int BK = 2 * F::KC;      // K elements per LDS stage = 128 bytes per row
   constexpr int LS = BK + E;         // LDS row stride (elements): +16 bytes keeps ds_read_b128 conflict-free
   constexpr int CPR = BK / E;        // 16-byte chunks per row (8)
-  constexpr int NT = BN / 16;        // 16-channel tiles per wave
   constexpr int A_LOADS = (GM_BM * CPR) / GM_THREADS;  // 2
-  constexpr int B_LOADS = (BN * CPR) / GM_THREADS;     // BN/32
+  constexpr int B_LOADS = (BN * CPR) / GM_THREADS;     // NT/2
   __shared__ __attribute__((aligned(16))) T sA[GM_BM * LS];
   __shared__ __attribute__((aligned(16))) T sB[BN * LS];
 
@@ -262,12 +263,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int spli
 
 static int bk_of(int dtype) { return dtype == PTV3_F32 ? 32 : 64; }
 
+// 16-channel tiles per workgroup column block.  Measured on MI355X over every linear shape of the fork config
+// (tools/bench_gemm.py): 64-channel blocks (NT = 4) are fastest or tied everywhere; wider blocks lose to the
+// longer per-wave epilogue and the lower workgroup count.  32-channel blocks only for narrow outputs.
+static int choose_nt(int cout) {
+  static const int opts[] = {2, 4, 6, 8, 12, 16};
+  if (const char* e = getenv("PTV3_GEMM_NT")) {  // tuning override (tools/bench_gemm.py)
+    int v = atoi(e);
+    for (int nt : opts) if (nt == v) return v;
+  }
+  return cout <= 32 ? 2 : 4;
+}
+
 // split decision shared by the workspace query and the launcher
 static int choose_splits(int64_t m, int cin, int cout, int kvol, int dtype, int* steps_per_split) {
   const int bk = bk_of(dtype);
   const int64_t ktot = (int64_t)kvol * cin;
   const int nsteps = (int)((ktot + bk - 1) / bk);
-  const int bn = (cout % 64 == 0) ? 64 : 32;
+  const int bn = 16 * choose_nt(cout);
   const int64_t base = cdiv(m, GM_BM) * cdiv(cout, bn);
   int splits = 1;
   if (nsteps >= 16 && base < 512) {
@@ -315,20 +328,25 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
              splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps};
   hipStream_t s = (hipStream_t)stream;
-  const int bn = (cout % 64 == 0) ? 64 : 32;
+  const int nt = choose_nt(cout);
+  const int bn = 16 * nt;
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, nbr ? PROF_SUBM_CONV : PROF_LINEAR, 2.0 * m * kvol * cin * cout,
                               ((double)m * cin * (nbr ? 1 : kvol) + (double)cout * kvol * cin +
                                (double)m * cout * (1 + (res != nullptr) + (out2 != nullptr))) * esz,
                               nbr, m * kvol, 2.0 * cin * cout);
   dim3 grid((unsigned)cdiv(m, GM_BM), (unsigned)cdiv(cout, bn), (unsigned)splits);
-  if (dtype == PTV3_F32) {
-    if (bn == 64) hipLaunchKernelGGL((gemm_kernel<float, 64>), grid, dim3(GM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<float, 32>), grid, dim3(GM_THREADS), 0, s, a);
-  } else {
-    if (bn == 64) hipLaunchKernelGGL((gemm_kernel<__bf16, 64>), grid, dim3(GM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<__bf16, 32>), grid, dim3(GM_THREADS), 0, s, a);
+#define GM_LAUNCH(T)                                                                                   \
+  switch (nt) {                                                                                        \
+    case 2: hipLaunchKernelGGL((gemm_kernel<T, 2>), grid, dim3(GM_THREADS), 0, s, a); break;           \
+    case 4: hipLaunchKernelGGL((gemm_kernel<T, 4>), grid, dim3(GM_THREADS), 0, s, a); break;           \
+    case 6: hipLaunchKernelGGL((gemm_kernel<T, 6>), grid, dim3(GM_THREADS), 0, s, a); break;           \
+    case 8: hipLaunchKernelGGL((gemm_kernel<T, 8>), grid, dim3(GM_THREADS), 0, s, a); break;           \
+    case 12: hipLaunchKernelGGL((gemm_kernel<T, 12>), grid, dim3(GM_THREADS), 0, s, a); break;         \
+    default: hipLaunchKernelGGL((gemm_kernel<T, 16>), grid, dim3(GM_THREADS), 0, s, a); break;         \
   }
+  if (dtype == PTV3_F32) { GM_LAUNCH(float) } else { GM_LAUNCH(__bf16) }
+#undef GM_LAUNCH
   if (splits > 1) {
     GemmArgs r = a;
     r.row_order = nullptr;  // slabs are indexed by output row already

@@ -135,10 +135,13 @@ pool_feat_kernel(const T* __restrict__ feat, const int64_t* __restrict__ order0,
   }
 }
 
+struct RowPerm { int v[8]; };
+
 __global__ void pool_meta_kernel(const float* __restrict__ coord, const int64_t* __restrict__ grid_coord,
                                  const int64_t* __restrict__ batch, const int64_t* __restrict__ code, int k,
                                  const int64_t* __restrict__ order0, const int32_t* __restrict__ seg_start,
-                                 int64_t n, int64_t n_out, int pooling_depth, float* __restrict__ coord_out,
+                                 int64_t n, int64_t n_out, int pooling_depth, RowPerm perm,
+                                 float* __restrict__ coord_out,
                                  int64_t* __restrict__ grid_out, int64_t* __restrict__ batch_out,
                                  int64_t* __restrict__ code_out) {
   int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,7 +161,10 @@ __global__ void pool_meta_kernel(const float* __restrict__ coord, const int64_t*
   grid_out[3 * j + 1] = grid_coord[3 * head + 1] >> pooling_depth;
   grid_out[3 * j + 2] = grid_coord[3 * head + 2] >> pooling_depth;
   batch_out[j] = batch[head];
-  for (int r = 0; r < k; ++r) code_out[(int64_t)r * n_out + j] = code[(int64_t)r * n + head] >> (3 * pooling_depth);
+  for (int r = 0; r < k; ++r) {
+    const int src = perm.v[r];  // output row r takes source row perm[r] (the order shuffle of :408-412)
+    code_out[(int64_t)r * n_out + j] = code[(int64_t)src * n + head] >> (3 * pooling_depth);
+  }
 }
 
 }  // namespace ptv3
@@ -220,9 +226,17 @@ static int launch_pool_feat(const void* feat, const int64_t* order0, const int32
 extern "C" int ptv3_pool_reduce(const void* feat, const float* coord, const int64_t* grid_coord,
                                 const int64_t* batch, const int64_t* code, int k, const int64_t* order0,
                                 const int32_t* seg_start, int64_t n, int64_t n_out, int c, int pooling_depth,
-                                const float* bn_scale, const float* bn_shift, int act, void* feat_out,
-                                float* coord_out, int64_t* grid_out, int64_t* batch_out, int64_t* code_out,
-                                int dtype, void* stream) {
+                                const float* bn_scale, const float* bn_shift, int act, const int* row_perm_host,
+                                void* feat_out, float* coord_out, int64_t* grid_out, int64_t* batch_out,
+                                int64_t* code_out, int dtype, void* stream) {
+  PTV3_REQUIRE(k >= 1 && k <= 8, "pool_reduce: k=%d outside [1,8]", k);
+  RowPerm perm;
+  for (int r = 0; r < 8; ++r) perm.v[r] = r;
+  if (row_perm_host)
+    for (int r = 0; r < k; ++r) {
+      PTV3_REQUIRE(row_perm_host[r] >= 0 && row_perm_host[r] < k, "pool_reduce: bad row permutation");
+      perm.v[r] = row_perm_host[r];
+    }
   PTV3_REQUIRE(c > 0 && c % 4 == 0, "pool_reduce: c=%d must be a multiple of 4", c);
   PTV3_REQUIRE((bn_scale == nullptr) == (bn_shift == nullptr), "pool_reduce: bn_scale/bn_shift must come together");
   PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "pool_reduce: bad dtype");
@@ -233,7 +247,7 @@ extern "C" int ptv3_pool_reduce(const void* feat, const float* coord, const int6
                : launch_pool_feat<__bf16>(feat, order0, seg_start, n_out, c, bn_scale, bn_shift, act, feat_out, s);
   if (rc) return rc;
   hipLaunchKernelGGL(pool_meta_kernel, dim3((unsigned)cdiv(n_out, 256)), dim3(256), 0, s, coord, grid_coord, batch,
-                     code, k, order0, seg_start, n, n_out, pooling_depth, coord_out, grid_out, batch_out, code_out);
+                     code, k, order0, seg_start, n, n_out, pooling_depth, perm, coord_out, grid_out, batch_out, code_out);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -263,9 +263,62 @@ __global__ void window_maps_kernel(const int64_t* __restrict__ order, const int6
   if (i < n) wi[i] = (int32_t)unpad[inverse[i]];
 }
 
+// pad plan and both window maps for all k orders in one pass, without materialising pad / unpad
+__global__ void window_plan_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ inverse,
+                                   const int64_t* __restrict__ offset, int b, int k, int64_t n, int64_t n_pad,
+                                   int K, int32_t* __restrict__ wo, int32_t* __restrict__ wi) {
+  extern __shared__ int64_t tab[];
+  int64_t* s_off = tab;
+  int64_t* s_offp = tab + (b + 1);
+  if (threadIdx.x == 0) {
+    int64_t prev = 0, prevp = 0;
+    s_off[0] = 0; s_offp[0] = 0;
+    for (int i = 0; i < b; ++i) {
+      int64_t cnt = offset[i] - prev;
+      int64_t cp = cnt > K ? (cnt + K - 1) / K * K : cnt;
+      prev = offset[i]; prevp += cp;
+      s_off[i + 1] = prev; s_offp[i + 1] = prevp;
+    }
+  }
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_pad) {
+    int lo = 0, hi = b;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_offp[mid] <= p) lo = mid; else hi = mid; }
+    const int64_t cnt = s_off[lo + 1] - s_off[lo], cntp = s_offp[lo + 1] - s_offp[lo];
+    const int64_t local = p - s_offp[lo];
+    int64_t src = local;
+    if (cnt != cntp && local >= cntp - K + cnt % K) src = local - K;
+    const int64_t pos = s_off[lo] + src;  // = pad[p]
+    for (int r = 0; r < k; ++r) wo[(int64_t)r * n_pad + p] = (int32_t)order[(int64_t)r * n + pos];
+  }
+  if (p < n) {
+    for (int r = 0; r < k; ++r) {
+      const int64_t j = inverse[(int64_t)r * n + p];  // serialized position of point p in order r
+      int lo = 0, hi = b;
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_off[mid] <= j) lo = mid; else hi = mid; }
+      wi[(int64_t)r * n + p] = (int32_t)(j + (s_offp[lo] - s_off[lo]));  // = unpad[j]
+    }
+  }
+}
+
 }  // namespace ptv3
 
 using namespace ptv3;
+
+extern "C" int ptv3_window_plan(const int64_t* order, const int64_t* inverse, const int64_t* offset, int b, int k,
+                                int64_t n, int64_t n_pad, int patch, int32_t* win_order, int32_t* win_inverse,
+                                void* stream) {
+  PTV3_REQUIRE(b >= 1 && b <= 4096, "window_plan: batch size %d outside [1,4096]", b);
+  PTV3_REQUIRE(k >= 1 && k <= 8 && patch >= 1, "window_plan: bad k / patch");
+  int64_t work = n_pad > n ? n_pad : n;
+  if (work == 0) return PTV3_OK;
+  hipLaunchKernelGGL(window_plan_kernel, dim3((unsigned)cdiv(work, 256)), dim3(256),
+                     (size_t)2 * (b + 1) * sizeof(int64_t), (hipStream_t)stream, order, inverse, offset, b, k, n, n_pad,
+                     patch, win_order, win_inverse);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
 
 extern "C" int ptv3_sfc_encode(const void* grid_coord, int coord_is_i64, const int64_t* batch, int64_t n,
                                int depth, const int* order_ids_host, int k, int64_t* code, void* stream) {

@@ -293,8 +293,7 @@ class SerializedPooling(PointModule):
             # come out already permuted
             perm = torch.randperm(k).tolist()
         else:
-            perm = list(range(k))
-        code_src = code if perm == list(range(k)) else code[torch.tensor(perm, device=code.device)]
+            perm = None
         # folded BN + activation ride on the segmented max when they are the standard eval layers
         bn = self.norm[0] if self.norm is not None and len(self.norm) == 1 and isinstance(self.norm[0], BatchNorm1d) else None
         act_id = ops.ACT_NONE
@@ -307,8 +306,9 @@ class SerializedPooling(PointModule):
         proj = self.proj(point.feat)
         feat, coord, grid_coord, batch, code_out = ops.pool_reduce(
             proj, point.coord.float().contiguous() if "coord" in point.keys() else None,
-            point.grid_coord.long().contiguous(), point.batch.long().contiguous(), code_src, order0, seg_start,
-            n_out, pooling_depth, bn_scale=scale, bn_shift=shift, act=act_id if fuse else ops.ACT_NONE)
+            point.grid_coord.long().contiguous(), point.batch.long().contiguous(), code, order0, seg_start,
+            n_out, pooling_depth, bn_scale=scale, bn_shift=shift, act=act_id if fuse else ops.ACT_NONE,
+            row_perm=perm)
         depth = point.serialized_depth - pooling_depth
         end_bit = max(1, depth * 3 + max(nb - 1, 0).bit_length())
         order, inverse = ops.argsort_codes(code_out, end_bit)

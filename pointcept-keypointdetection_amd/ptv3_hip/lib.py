@@ -24,6 +24,7 @@ SIGNATURES = {
     "ptv3_argsort_i64": (c_int, [P, c_int, c_int64, c_int, P, P, P, c_size_t, P]),
     "ptv3_pad_plan": (c_int, [P, c_int, c_int64, c_int64, c_int, P, P, P, P]),
     "ptv3_window_maps": (c_int, [P, P, P, P, c_int64, c_int64, P, P, P]),
+    "ptv3_window_plan": (c_int, [P, P, P, c_int, c_int, c_int64, c_int64, c_int, P, P, P]),
     "ptv3_window_attn_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, P, c_int, P]),
     "ptv3_subm_table_slots": (c_int64, [c_int64]),
     "ptv3_subm_build_table": (c_int, [P, c_int64, P, c_int64, P]),
@@ -37,7 +38,7 @@ SIGNATURES = {
     "ptv3_pool_workspace_bytes": (c_size_t, [c_int64]),
     "ptv3_pool_segments": (c_int, [P, P, c_int64, c_int, P, P, P, P, P, P, c_size_t, P]),
     "ptv3_pool_reduce": (c_int, [P, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, P, P, c_int, P, P, P,
-                                 P, P, c_int, P]),
+                                 P, P, P, c_int, P]),
     "ptv3_forward_workspace_bytes": (c_size_t, [P, c_int64, c_int]),
     "ptv3_forward": (c_int, [P, P, c_int, P, P, c_size_t, P]),
     "ptv3_profile_enable": (c_int, [c_int]),

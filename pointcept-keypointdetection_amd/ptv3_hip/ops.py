@@ -107,6 +107,24 @@ def window_maps(order, inverse, pad, unpad):
     return wo, wi
 
 
+def window_plan(order, inverse, offset, offset_host, patch):
+    """(win_order (k, n_pad), win_inverse (k, n)) int32 for all k orders in one launch."""
+    _chk(order, "order", torch.int64, 2)
+    _chk(inverse, "inverse", torch.int64, 2)
+    _chk(offset, "offset", torch.int64, 1)
+    k, n = order.shape
+    prev, n_pad = 0, 0
+    for o in offset_host:
+        cnt = o - prev
+        n_pad += (cnt + patch - 1) // patch * patch if cnt > patch else cnt
+        prev = o
+    wo = torch.empty((k, n_pad), dtype=torch.int32, device=order.device)
+    wi = torch.empty((k, n), dtype=torch.int32, device=order.device)
+    lib.check(lib.ptv3_window_plan(_p(order), _p(inverse), _p(offset), len(offset_host), k, n, n_pad, int(patch),
+                                   _p(wo), _p(wi), _stream()), "ptv3_window_plan")
+    return wo, wi
+
+
 def window_attention(qkv, win_order, win_inverse, heads, patch, scale, rpe_bias=None):
     """softmax(scale q k^T) v per window with gather/scatter fused (v3m1_base.py:188-216)."""
     _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
@@ -252,7 +270,7 @@ def pool_segments(code0, order0, shift_bits, batch=None, num_scenes=0):
 
 
 def pool_reduce(feat, coord, grid_coord, batch, code, order0, seg_start, n_out, pooling_depth, bn_scale=None,
-                bn_shift=None, act=ACT_NONE):
+                bn_shift=None, act=ACT_NONE, row_perm=None):
     _chk(feat, "feat", (torch.float32, torch.bfloat16), 2)
     _chk(coord, "coord", torch.float32, 2)
     _chk(grid_coord, "grid_coord", torch.int64, 2)
@@ -270,7 +288,8 @@ def pool_reduce(feat, coord, grid_coord, batch, code, order0, seg_start, n_out, 
     code_out = torch.empty((k, n_out), dtype=torch.int64, device=dev)
     lib.check(lib.ptv3_pool_reduce(_p(feat), _p(coord), _p(grid_coord), _p(batch), _p(code), k, _p(order0),
                                    _p(seg_start), n, n_out, c, int(pooling_depth), _p(bn_scale), _p(bn_shift),
-                                   int(act), _p(feat_out), _p(coord_out), _p(grid_out), _p(batch_out), _p(code_out),
+                                   int(act), (ctypes.c_int * k)(*row_perm) if row_perm is not None else None,
+                                   _p(feat_out), _p(coord_out), _p(grid_out), _p(batch_out), _p(code_out),
                                    _dt(feat), _stream()), "ptv3_pool_reduce")
     return feat_out, coord_out, grid_out, batch_out, code_out
 

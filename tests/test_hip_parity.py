@@ -118,6 +118,9 @@ def test_window_attention_golden_fp32(dev, golden_dir, case):
     wo, wi = ops.window_maps(to(c["order"]), to(c["inverse"]), to(c["pad"]), to(c["unpad"]))
     assert np.array_equal(wo.cpu().numpy(), c["order"][c["pad"]])
     assert np.array_equal(wi.cpu().numpy(), c["unpad"][c["inverse"]])
+    # the one-launch plan used by the native executor gives the same maps
+    wo2, wi2 = ops.window_plan(to(c["order"])[None], to(c["inverse"])[None], to(c["off"]), c["off"].tolist(), c["K"])
+    assert torch.equal(wo2[0], wo) and torch.equal(wi2[0], wi)
     out = ops.window_attention(to(c["qkv"]), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
     core = O.window_attention_core(torch.from_numpy(c["qkv"]), torch.from_numpy(c["order"]),
                                    torch.from_numpy(c["inverse"]), torch.from_numpy(c["pad"]),
