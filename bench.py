@@ -132,6 +132,7 @@ def main():
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.backbone.compute_dtype = dtype
+    model.backbone.inputs_resident = True  # the scene batch sits in HBM before the timed region (bench contract)
     # every rank owns its own scene(s): shard = scene, no exchange on the data path
     scenes = [S.make_scene(args.points, 4, None, seed, args.kind) for seed in rank_scene_seeds(rank, args.scenes)]
     batch = {k: v.to(device) for k, v in S.collate(scenes).items()}

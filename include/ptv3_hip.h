@@ -152,7 +152,9 @@ int ptv3_pool_segments(const int64_t* code0, const int64_t* order0, int64_t n, i
  *   coord_out[j] = mean_members(coord[.])                                  (n_out, 3) fp32
  *   head = first member: grid_out[j] = grid_coord[head] >> pooling_depth (int64), batch_out[j] =
  *   batch[head], code_out[r][j] = code[perm[r]][head] >> 3*pooling_depth for r < k, where perm is the
- *   order shuffle of :408-412 (row_perm_host, k host ints; NULL = identity). */
+ *   order shuffle of :408-412 (row_perm_host, k host ints; NULL = identity).
+ *   feat == NULL skips the feature half, grid_coord == NULL skips the geometry half (the executor runs the
+ *   two halves on different streams). */
 int ptv3_pool_reduce(const void* feat, const float* coord, const int64_t* grid_coord,
                      const int64_t* batch, const int64_t* code, int k, const int64_t* order0,
                      const int32_t* seg_start, int64_t n, int64_t n_out, int c, int pooling_depth,
@@ -187,16 +189,22 @@ typedef struct {
 typedef struct {
   const void* grid_coord; int32_t coord_is_i64; /* (n,3) */
   const void* feat;                             /* (n, in_channels) dtype */
-  const int64_t* batch;                         /* (n) */
+  const int64_t* batch;                         /* (n), or NULL: derived from offset (misc.py:25-30) */
   const int64_t* offset;                        /* (b) cumulative, device */
-  const int64_t* offset_host;                   /* (b) same values, host */
-  int32_t b; int64_t n; int32_t depth;          /* depth = bit_length(max(grid_coord)+1) (structure.py:73) */
+  const int64_t* offset_host;                   /* (b) same values on the host, or NULL: read back internally */
+  int32_t b; int64_t n;
+  int32_t depth;                                /* bit_length(max(grid_coord)+1) (structure.py:73); 0: computed */
   const int32_t* order_ids_host;                /* num_orders curve ids, already in shuffled order */
   const int32_t* pool_perm_host;                /* (num_stages-1, num_orders) row permutations (:408-412) */
   int64_t *code, *order, *inverse;              /* out: (num_orders, n) level-0 serialization */
   void* out_feat;                               /* out: (n, dec_channels[0]) dtype */
   float* out_head;                              /* out: (n, head_out) fp32 (head_out > 0) */
   int64_t* stage_points_host;                   /* out, optional: num_stages point counts */
+  int32_t* depth_out;                           /* out, optional: the serialization depth used */
+  int64_t* batch_out;                           /* out, optional (batch == NULL): (n) derived batch ids */
+  int32_t inputs_resident;                      /* 1: grid_coord / batch / offset were complete in memory before
+                                                   this call (not produced on `stream` just now): the geometry
+                                                   pipeline may then overlap the previous call's feature tail */
 } ptv3_forward_io;
 
 size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b);

@@ -1,10 +1,17 @@
 // Whole-model forward executor: PointTransformerV3.forward (+ optional dense head) as ONE C-ABI call.
-// The per-op entry points of include/ptv3_hip.h are launched back to back from native code (no
-// interpreter between launches); device memory comes from one caller-provided arena; the only
-// host<->device round trips are the pooled scene offsets after each SerializedPooling (4 per forward),
-// which the reference also needs (torch.unique) to size the next stage.
-// Mirrors point_transformer_v3m1_base.py:699-714 -> Embedding :485-515, Block :318-338,
-// SerializedPooling :371-444, SerializedUnpooling :471-482 in eval mode.
+//
+// Two HIP streams.  Everything that depends only on the coordinates (serialization, radix sorts, pooling
+// clusters for every level, site hashes, neighbour tables, window plans) is the GEOMETRY pipeline and runs
+// on an internal stream; everything that touches features runs on the caller's stream.  The only host
+// round trips (pooled scene offsets after each SerializedPooling: the reference's torch.unique needs the
+// same) wait on the geometry stream alone, so they never drain the feature stream: while the level-0
+// blocks execute, the host has already sized and queued the deeper levels.  Cross-stream order is by
+// events (one per level).  Device memory comes from one caller-provided arena, split into a geometry
+// part (never reused inside a call: the two streams run concurrently) and a feature part (stack).
+//
+// Mirrors point_transformer_v3m1_base.py:699-714 -> structure.py:52-146, Embedding :485-515,
+// Block :318-338, SerializedPooling :371-444, SerializedUnpooling :471-482 in eval mode.
+#include <algorithm>
 #include <vector>
 #include "common.h"
 #include "../../include/ptv3_hip.h"
@@ -48,6 +55,30 @@ __global__ void i64_to_i32_kernel(const int64_t* __restrict__ src, int32_t* __re
   if (i < n) dst[i] = (int32_t)src[i];
 }
 
+// max over all 3n grid coordinates -> out[0] (for depth = bit_length(max + 1), structure.py:73)
+__global__ void coord_max_kernel(const void* __restrict__ grid, int is_i64, int64_t n3, int* __restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int v = 0;
+  for (; i < n3; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t c = is_i64 ? ((const int64_t*)grid)[i] : (int64_t)((const int32_t*)grid)[i];
+    v = max(v, (int)c);
+  }
+  for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_down(v, d, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out, v);
+}
+
+// batch[i] = scene of point i, from the cumulative offsets (offset2batch, models/utils/misc.py:25-30)
+__global__ void batch_from_offset_kernel(const int64_t* __restrict__ offset, int b, int64_t n,
+                                         int64_t* __restrict__ batch) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int lo = 0, hi = b;  // first scene whose end is > i
+  while (lo < hi) { int mid = (lo + hi) >> 1; if (offset[mid] > i) hi = mid; else lo = mid + 1; }
+  batch[i] = lo;
+}
+
+struct Plan { int K = -1; int64_t n_pad = 0; int32_t* wo[8] = {nullptr}; int32_t* wi[8] = {nullptr}; };
+
 struct Level {
   int64_t n = 0; int depth = 0;
   std::vector<int64_t> off_host;
@@ -55,76 +86,99 @@ struct Level {
   const int64_t* grid = nullptr; const int64_t* batch = nullptr;
   int64_t *code = nullptr, *order = nullptr, *inverse = nullptr;
   int32_t* indices = nullptr; void* table = nullptr; int64_t slots = 0;
-  int32_t* nbr3 = nullptr; int32_t* row_order = nullptr;
-  int K = -1; int64_t n_pad = 0; int64_t *pad = nullptr, *unpad = nullptr; int32_t* cu = nullptr;
-  int32_t* wo[8] = {nullptr}; int32_t* wi[8] = {nullptr};
+  int32_t* nbr3 = nullptr; int32_t* nbr5 = nullptr; int32_t* row_order = nullptr;
+  Plan plan[2];                 // [0] encoder patch, [1] decoder patch (shared when K is equal)
+  int32_t* seg = nullptr;       // runs of THIS level's points in order 0 that form the next level's rows
+  int64_t* cluster = nullptr;   // pooling_inverse: this level's point -> next level's row
+  int32_t* cluster32 = nullptr;
+  hipEvent_t ready = nullptr;   // geometry of this level complete (recorded on the geometry stream)
   void* feat = nullptr; void* conv_feat = nullptr; int channels = 0;
-  int64_t* cluster = nullptr;  // pooling_inverse of the PARENT's points into this level
 };
 
+static hipStream_t g_geo_stream = nullptr;
+static std::vector<hipEvent_t> g_events;
+static unsigned g_call = 0;  // calls alternate between the two geometry arenas (see ptv3_forward)
+
+static hipEvent_t event_at(size_t i) {
+  while (g_events.size() <= i) {
+    hipEvent_t e;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    g_events.push_back(e);
+  }
+  return g_events[i];
+}
+
 struct Run {
-  const ptv3_model_desc* d; const void* const* params; int pi = 0; Arena* A; hipStream_t s; int es; bool dry;
-  int rc = 0;
+  const ptv3_model_desc* d; const void* const* params; int pi = 0;
+  Arena* G; Arena* F;            // geometry / feature arenas
+  hipStream_t sg, sf;            // geometry / feature streams
+  int es; bool dry; int rc = 0;
   const void* next() { return params ? params[pi++] : (pi++, nullptr); }
-  void* alloc(size_t b) { return A->alloc(b); }
-  bool ok() const { return rc == 0 && !A->failed; }
+  bool ok() const { return rc == 0 && !G->failed && !F->failed; }
 #define RUN(call) do { if (!dry && ok()) { int r__ = (call); if (r__) rc = r__; } } while (0)
 
   void gemm(const void* x, const void* w, void* out, int64_t m, int cin, int cout, int kvol, const int32_t* nbr,
             const int32_t* row_order, const float* bias, const float* bns, const float* bnt, int act,
             const void* res, const int32_t* res_index, void* out2) {
     size_t wsb = ptv3_gemm_workspace_bytes(m, cin, cout, kvol, d->dtype);
-    size_t mark = A->off;
-    void* ws = wsb ? alloc(wsb) : nullptr;
+    size_t mark = F->off;
+    void* ws = wsb ? F->alloc(wsb) : nullptr;
     RUN(ptv3_gemm(x, w, out, m, cin, cout, kvol, nbr, row_order, bias, bns, bnt, act, res, res_index, out2,
-                  d->dtype, ws, wsb, s));
-    A->off = mark;  // stream order makes immediate reuse safe
+                  d->dtype, ws, wsb, sf));
+    F->off = mark;  // stream order makes immediate reuse safe
   }
 
-  void prepare_sites(Level& L, const void* grid_in, int is_i64, bool need_grid64) {
-    L.indices = (int32_t*)alloc((size_t)L.n * 16);
-    L.row_order = (int32_t*)alloc((size_t)L.n * 4);
+  int patch_K(const Level& L, int patch) const {
+    if (d->enable_flash) return patch;
+    int64_t mn = L.off_host[0];
+    for (size_t i = 1; i < L.off_host.size(); ++i) mn = std::min(mn, L.off_host[i] - L.off_host[i - 1]);
+    return (int)std::min<int64_t>(mn, patch);
+  }
+
+  void window_plan(Level& L, Plan& P, int K) {
+    int64_t n_pad = 0, prev = 0;
+    for (int64_t o : L.off_host) {
+      int64_t cnt = o - prev;
+      n_pad += cnt > K ? (cnt + K - 1) / K * K : cnt;
+      prev = o;
+    }
+    P.K = K; P.n_pad = n_pad;
+    const int k = d->num_orders;
+    int32_t* wo = (int32_t*)G->alloc((size_t)k * n_pad * 4);
+    int32_t* wi = (int32_t*)G->alloc((size_t)k * L.n * 4);
+    RUN(ptv3_window_plan(L.order, L.inverse, L.offset, (int)L.off_host.size(), k, L.n, n_pad, K, wo, wi, sg));
+    for (int i = 0; i < k; ++i) { P.wo[i] = wo + (int64_t)i * n_pad; P.wi[i] = wi + (int64_t)i * L.n; }
+  }
+
+  // sites, hash, neighbour tables and window plans of one level (geometry stream)
+  void level_geometry(Level& L, int st, const void* grid_in, int is_i64, bool need_grid64) {
+    L.indices = (int32_t*)G->alloc((size_t)L.n * 16);
+    L.row_order = (int32_t*)G->alloc((size_t)L.n * 4);
     int64_t* g64 = nullptr;
-    if (need_grid64) { g64 = (int64_t*)alloc((size_t)L.n * 24); L.grid = g64; }
+    if (need_grid64) { g64 = (int64_t*)G->alloc((size_t)L.n * 24); L.grid = g64; }
     if (!dry && ok())
-      hipLaunchKernelGGL(make_indices_kernel, dim3((unsigned)cdiv(L.n, 256)), dim3(256), 0, s, L.batch, grid_in, is_i64,
+      hipLaunchKernelGGL(make_indices_kernel, dim3((unsigned)cdiv(L.n, 256)), dim3(256), 0, sg, L.batch, grid_in, is_i64,
                          L.n, L.indices, g64, L.row_order, L.order);
     L.slots = ptv3_subm_table_slots(L.n);
-    L.table = alloc((size_t)L.slots * 12);
-    RUN(ptv3_subm_build_table(L.indices, L.n, L.table, L.slots, s));
+    L.table = G->alloc((size_t)L.slots * 12);
+    RUN(ptv3_subm_build_table(L.indices, L.n, L.table, L.slots, sg));
+    if (st == 0) {
+      L.nbr5 = (int32_t*)G->alloc((size_t)L.n * 125 * 4);
+      RUN(ptv3_subm_neighbors(L.indices, L.n, L.table, L.slots, 5, L.nbr5, sg));
+    }
+    L.nbr3 = (int32_t*)G->alloc((size_t)L.n * 27 * 4);
+    RUN(ptv3_subm_neighbors(L.indices, L.n, L.table, L.slots, 3, L.nbr3, sg));
+    const int Ke = patch_K(L, d->enc_patch[st]);
+    window_plan(L, L.plan[0], Ke);
+    if (!d->enc_mode && st < d->num_stages - 1) {
+      const int Kd = patch_K(L, d->dec_patch[st]);
+      if (Kd == Ke) L.plan[1] = L.plan[0]; else window_plan(L, L.plan[1], Kd);
+    }
   }
 
-  void attention_plan(Level& L, int patch, int oi) {
-    int K = patch;
-    if (!d->enable_flash) {
-      int64_t mn = L.off_host[0];
-      for (size_t i = 1; i < L.off_host.size(); ++i) mn = std::min(mn, L.off_host[i] - L.off_host[i - 1]);
-      K = (int)std::min<int64_t>(mn, patch);
-    }
-    if (K != L.K) {
-      int64_t n_pad = 0, prev = 0;
-      for (int64_t o : L.off_host) {
-        int64_t cnt = o - prev;
-        n_pad += cnt > K ? (cnt + K - 1) / K * K : cnt;
-        prev = o;
-      }
-      L.K = K; L.n_pad = n_pad;
-      // one launch: pad plan + both window maps of every order (:114-170, :184-185)
-      const int k = d->num_orders;
-      int32_t* wo = (int32_t*)alloc((size_t)k * n_pad * 4);
-      int32_t* wi = (int32_t*)alloc((size_t)k * L.n * 4);
-      RUN(ptv3_window_plan(L.order, L.inverse, L.offset, (int)L.off_host.size(), k, L.n, n_pad, K, wo, wi, s));
-      for (int i = 0; i < 8; ++i) {
-        L.wo[i] = i < k ? wo + (int64_t)i * n_pad : nullptr;
-        L.wi[i] = i < k ? wi + (int64_t)i * L.n : nullptr;
-      }
-    }
-    (void)oi;
-  }
-
-  // Block.forward (:318-338), eval, pre_norm; writes the new features into `L.feat` (same buffer)
-  void block(Level& L, int C, int H, int patch, int oi) {
-    const void* conv_w = next(); const float* conv_b = (const float*)next();  // cpe Linear folded in
+  // Block.forward (:318-338), eval, pre_norm; cpe Linear folded into the conv taps
+  void block(Level& L, const Plan& P, int C, int H, int oi) {
+    const void* conv_w = next(); const float* conv_b = (const float*)next();
     const float* ln0_g = (const float*)next(); const float* ln0_b = (const float*)next();
     const float* n1_g = (const float*)next(); const float* n1_b = (const float*)next();
     const void* qkv_w = next(); const float* qkv_b = (const float*)next();
@@ -133,132 +187,179 @@ struct Run {
     const void* fc1_w = next(); const float* fc1_b = (const float*)next();
     const void* fc2_w = next(); const float* fc2_b = (const float*)next();
     const int hidden = (int)(C * d->mlp_ratio);
-    if (!L.nbr3) {
-      L.nbr3 = (int32_t*)alloc((size_t)L.n * 27 * 4);
-      RUN(ptv3_subm_neighbors(L.indices, L.n, L.table, L.slots, 3, L.nbr3, s));
-    }
-    attention_plan(L, patch, oi);
-    const size_t mark = A->off;
+    const size_t mark = F->off;
     const size_t row = (size_t)L.n * es;
-    void* t2 = alloc(row * C); void* f1 = alloc(row * C); void* t3 = alloc(row * C);
-    void* qkv = alloc(row * 3 * C); void* t4 = alloc(row * C); void* f2 = alloc(row * C); void* t5 = alloc(row * C);
-    void* t6 = alloc(row * hidden);
+    void* t2 = F->alloc(row * C); void* f1 = F->alloc(row * C); void* t3 = F->alloc(row * C);
+    void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C); void* f2 = F->alloc(row * C);
+    void* t5 = F->alloc(row * C); void* t6 = F->alloc(row * hidden);
     gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-    RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, s));
+    RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
     gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     const float scale = d->qk_scale > 0.f ? d->qk_scale : 1.0f / sqrtf((float)(C / H));
-    RUN(ptv3_window_attn_fwd(qkv, L.wo[oi], L.wi[oi], t4, L.n, L.n_pad, C, H, L.K, scale, nullptr, d->dtype, s));
+    RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
     gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
-    RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, s));
+    RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, sf));
     gemm(t5, fc1_w, t6, L.n, C, hidden, 1, nullptr, nullptr, fc1_b, nullptr, nullptr, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
     gemm(t6, fc2_w, L.feat, L.n, hidden, C, 1, nullptr, nullptr, fc2_b, nullptr, nullptr, 0, f2, nullptr, nullptr);
     L.conv_feat = L.feat;
-    A->off = mark;
+    F->off = mark;
   }
 };
 
-static int run_forward(const ptv3_model_desc* d, const void* const* params, const ptv3_forward_io* io, Arena& A,
-                       hipStream_t s, bool dry, size_t* peak, int* param_count = nullptr) {
-  Run R; R.d = d; R.params = params; R.A = &A; R.s = s; R.dry = dry; R.es = d->dtype == PTV3_F32 ? 4 : 2;
+#define RUNR(call) do { if (!dry && R.ok()) { int r__ = (call); if (r__) R.rc = r__; } } while (0)
+
+static int run_forward(const ptv3_model_desc* d, const void* const* params, const ptv3_forward_io* io, Arena& G,
+                       Arena& F, hipStream_t sf, bool dry, int* param_count = nullptr) {
+  Run R; R.d = d; R.params = params; R.G = &G; R.F = &F; R.sf = sf; R.dry = dry;
+  R.es = d->dtype == PTV3_F32 ? 4 : 2;
   const int S = d->num_stages, k = d->num_orders, es = R.es;
-  std::vector<Level> lv(S);
-  // ---- level 0: serialization (structure.py:52-109)
-  Level& L0 = lv[0];
-  L0.n = io->n; L0.depth = io->depth; L0.batch = io->batch; L0.offset = io->offset;
-  L0.off_host.assign(io->offset_host, io->offset_host + io->b);
-  L0.code = io->code; L0.order = io->order; L0.inverse = io->inverse;
-  const int nbits = io->b > 1 ? 32 - __builtin_clz((unsigned)(io->b - 1)) : 0;
-  {
-    if (!dry) { int r = ptv3_sfc_encode(io->grid_coord, io->coord_is_i64, io->batch, io->n, io->depth,
-                                        io->order_ids_host, k, L0.code, s); if (r) return r; }
-    size_t wsb = ptv3_argsort_workspace_bytes(k, io->n);
-    size_t mark = A.off;
-    void* ws = A.alloc(wsb);
-    if (!dry && !A.failed) { int r = ptv3_argsort_i64(L0.code, k, io->n, std::max(1, 3 * io->depth + nbits), L0.order,
-                                                      L0.inverse, ws, wsb, s); if (r) return r; }
-    A.off = mark;
+  if (!dry) {
+    if (!g_geo_stream && hipStreamCreateWithFlags(&g_geo_stream, hipStreamNonBlocking) != hipSuccess) {
+      set_error("forward: cannot create the geometry stream");
+      return PTV3_ERR_LAUNCH;
+    }
+    if (!io->inputs_resident) {
+      // coordinates / offsets may have been produced on the caller's stream just before this call
+      hipEvent_t e = event_at(0);
+      (void)hipEventRecord(e, sf);
+      (void)hipStreamWaitEvent(g_geo_stream, e, 0);
+    } else {
+      // inputs already materialised: geometry of this call may overlap the feature tail of the previous one;
+      // it only has to wait for the call that last used THIS geometry arena (two calls ago)
+      (void)hipStreamWaitEvent(g_geo_stream, event_at(20 + (g_call & 1)), 0);
+    }
   }
-  R.prepare_sites(L0, io->grid_coord, io->coord_is_i64, true);
-  // ---- embedding (:485-515): SubMConv3d k=5 -> folded BN -> GELU
+  R.sg = g_geo_stream;
+  hipStream_t sg = R.sg;
+  std::vector<Level> lv(S);
+  const int nbits = io->b > 1 ? 32 - __builtin_clz((unsigned)(io->b - 1)) : 0;
+
+  // ---------------- level 0 geometry: depth, scene offsets, serialization (structure.py:52-109)
+  Level& L0 = lv[0];
+  L0.n = io->n; L0.batch = io->batch; L0.offset = io->offset;
+  L0.code = io->code; L0.order = io->order; L0.inverse = io->inverse;
+  L0.off_host.resize(io->b);
+  int depth = io->depth;
+  if (dry) {
+    for (int i = 0; i < io->b; ++i) L0.off_host[i] = io->offset_host ? io->offset_host[i] : io->n * (i + 1) / io->b;
+    if (depth <= 0) { depth = 16; G.alloc(256); }
+  } else {
+    int* dmax = nullptr;
+    if (depth <= 0) {
+      dmax = (int*)G.alloc(256);
+      if (G.failed) { set_error("forward: workspace arena too small"); return PTV3_ERR_ARG; }
+      (void)hipMemsetAsync(dmax, 0, 4, sg);
+      hipLaunchKernelGGL(coord_max_kernel, dim3(256), dim3(256), 0, sg, io->grid_coord, io->coord_is_i64, 3 * io->n, dmax);
+    }
+    int hmax = 0;
+    if (dmax) (void)hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, sg);
+    if (io->offset_host) std::copy(io->offset_host, io->offset_host + io->b, L0.off_host.begin());
+    else (void)hipMemcpyAsync(L0.off_host.data(), io->offset, (size_t)io->b * 8, hipMemcpyDeviceToHost, sg);
+    if (dmax || !io->offset_host) {
+      if (hipStreamSynchronize(sg) != hipSuccess) { set_error("forward: input read-back failed"); return PTV3_ERR_LAUNCH; }
+    }
+    if (dmax) { depth = 0; for (unsigned v = (unsigned)hmax + 1; v; v >>= 1) ++depth; }
+    PTV3_REQUIRE(depth >= 1 && depth <= 16, "forward: serialization depth %d outside [1,16] (structure.py:81)", depth);
+    for (int i = 0; i < io->b; ++i)
+      PTV3_REQUIRE(L0.off_host[i] > (i ? L0.off_host[i - 1] : 0), "forward: empty scene %d", i);
+    PTV3_REQUIRE(L0.off_host[io->b - 1] == io->n, "forward: offset does not end at n");
+  }
+  L0.depth = depth;
+  if (io->depth_out) *io->depth_out = depth;
+  if (io->batch == nullptr) {  // derive the batch ids on the geometry stream (no torch ops on the caller's stream)
+    int64_t* bt = io->batch_out ? io->batch_out : (int64_t*)G.alloc((size_t)io->n * 8);
+    if (!dry && R.ok())
+      hipLaunchKernelGGL(batch_from_offset_kernel, dim3((unsigned)cdiv(io->n, 256)), dim3(256), 0, sg, io->offset, io->b,
+                         io->n, bt);
+    L0.batch = bt;
+  }
   {
-    const void* w = R.next(); const float* bns = (const float*)R.next(); const float* bnt = (const float*)R.next();
+    RUNR(ptv3_sfc_encode(io->grid_coord, io->coord_is_i64, L0.batch, io->n, depth, io->order_ids_host, k, L0.code, sg));
+    size_t wsb = ptv3_argsort_workspace_bytes(k, io->n);
+    void* ws = G.alloc(wsb);
+    RUNR(ptv3_argsort_i64(L0.code, k, io->n, std::max(1, 3 * depth + nbits), L0.order, L0.inverse, ws, wsb, sg));
+  }
+  R.level_geometry(L0, 0, io->grid_coord, io->coord_is_i64, true);
+  if (io->stage_points_host) io->stage_points_host[0] = L0.n;
+  if (!dry && R.ok()) { L0.ready = event_at(1); (void)hipEventRecord(L0.ready, sg); }
+
+  // ---------------- features of level 0 start as soon as its geometry is queued
+  auto wait_level = [&](Level& L) { if (!dry && R.ok()) (void)hipStreamWaitEvent(sf, L.ready, 0); };
+  struct PoolParams { const void* w; const float *b, *bns, *bnt; };
+  // parameter walk order (header): stem, enc stage 0 blocks, [down, blocks] ..., decoder, head.
+  const void* stem_w = R.next(); const float* stem_s = (const float*)R.next(); const float* stem_t = (const float*)R.next();
+  {
+    wait_level(L0);
     const int C0 = d->enc_channels[0];
-    L0.feat = R.alloc((size_t)L0.n * C0 * es); L0.channels = C0;
-    const size_t mark = A.off;
-    int32_t* nbr5 = (int32_t*)R.alloc((size_t)L0.n * 125 * 4);
-    if (!dry && R.ok()) { int r = ptv3_subm_neighbors(L0.indices, L0.n, L0.table, L0.slots, 5, nbr5, s); if (r) R.rc = r; }
-    R.gemm(io->feat, w, L0.feat, L0.n, d->in_channels, C0, 125, nbr5, L0.row_order, nullptr, bns, bnt, PTV3_ACT_GELU,
-           nullptr, nullptr, nullptr);
-    A.off = mark;
+    L0.feat = F.alloc((size_t)L0.n * C0 * es); L0.channels = C0;
+    R.gemm(io->feat, stem_w, L0.feat, L0.n, d->in_channels, C0, 125, L0.nbr5, L0.row_order, nullptr, stem_s, stem_t,
+           PTV3_ACT_GELU, nullptr, nullptr, nullptr);
     L0.conv_feat = L0.feat;
   }
-  // ---- encoder
   for (int st = 0; st < S; ++st) {
     Level& L = lv[st];
     if (st > 0) {
       Level& P = lv[st - 1];
-      const void* w = R.next(); const float* b = (const float*)R.next();
-      const float* bns = (const float*)R.next(); const float* bnt = (const float*)R.next();
+      PoolParams pp;
+      pp.w = R.next(); pp.b = (const float*)R.next(); pp.bns = (const float*)R.next(); pp.bnt = (const float*)R.next();
       const int C = d->enc_channels[st], Cp = d->enc_channels[st - 1];
       int pd = 0; { int v = d->stride[st - 1] - 1; while (v > 0) { ++pd; v >>= 1; } }
       if (pd > P.depth) pd = 0;
-      P.cluster = (int64_t*)R.alloc((size_t)P.n * 8);
-      int64_t* poff = (int64_t*)R.alloc((size_t)io->b * 8);
-      void* proj = R.alloc((size_t)P.n * C * es);
-      R.gemm(P.feat, w, proj, P.n, Cp, C, 1, nullptr, nullptr, b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-      int32_t* seg = (int32_t*)R.alloc((size_t)(P.n + 1) * 4);
-      int32_t* nout_dev = (int32_t*)R.alloc(256);
+      // ---- geometry of the pooled level (geometry stream; its read-back never drains the feature stream)
+      P.cluster = (int64_t*)G.alloc((size_t)P.n * 8);
+      P.seg = (int32_t*)G.alloc((size_t)(P.n + 1) * 4);
+      int64_t* poff = (int64_t*)G.alloc((size_t)io->b * 8);
+      int32_t* nout_dev = (int32_t*)G.alloc(256);
       size_t pwsb = ptv3_pool_workspace_bytes(P.n);
-      void* pws = R.alloc(pwsb);
-      if (!dry && R.ok()) {
-        int r = ptv3_pool_segments(P.code, P.order, P.n, 3 * pd, P.batch, P.cluster, seg, nout_dev, poff, pws, pwsb, s);
-        if (r) R.rc = r;
-      }
+      void* pws = G.alloc(pwsb);
+      RUNR(ptv3_pool_segments(P.code, P.order, P.n, 3 * pd, P.batch, P.cluster, P.seg, nout_dev, poff, pws, pwsb, sg));
       L.off_host.resize(io->b);
       if (dry) {
         L.off_host = P.off_host;  // worst case: nothing merges
       } else if (R.ok()) {
-        // the one host round trip of the stage (the reference's torch.unique has the same)
-        if (hipMemcpyAsync(L.off_host.data(), poff, (size_t)io->b * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) { set_error("forward: offset read-back failed"); return PTV3_ERR_LAUNCH; }
+        if (hipMemcpyAsync(L.off_host.data(), poff, (size_t)io->b * 8, hipMemcpyDeviceToHost, sg) != hipSuccess ||
+            hipStreamSynchronize(sg) != hipSuccess) { set_error("forward: offset read-back failed"); return PTV3_ERR_LAUNCH; }
       }
       if (!R.ok()) break;
       L.n = L.off_host[io->b - 1]; L.depth = P.depth - pd; L.offset = poff; L.channels = C;
       if (io->stage_points_host) io->stage_points_host[st] = L.n;
       const int* perm = io->pool_perm_host + (size_t)(st - 1) * k;  // order shuffle of :408-412
-      // pooled level tensors (sized by the n_out just read back); the stage's temporaries simply stay
-      // allocated below them for the rest of the forward (a few MB)
-      L.feat = R.alloc((size_t)L.n * C * es);
-      int64_t* g = (int64_t*)R.alloc((size_t)L.n * 24);
-      int64_t* bt = (int64_t*)R.alloc((size_t)L.n * 8);
-      L.code = (int64_t*)R.alloc((size_t)k * L.n * 8);
-      L.order = (int64_t*)R.alloc((size_t)k * L.n * 8);
-      L.inverse = (int64_t*)R.alloc((size_t)k * L.n * 8);
-      if (!dry && R.ok()) {
-        int r = ptv3_pool_reduce(proj, nullptr, P.grid, P.batch, P.code, k, P.order, seg, P.n, L.n, C, pd, bns, bnt,
-                                 PTV3_ACT_GELU, perm, L.feat, nullptr, g, bt, L.code, d->dtype, s);
-        if (r) R.rc = r;
-      }
-      L.grid = g; L.batch = bt; L.conv_feat = L.feat;
+      int64_t* g = (int64_t*)G.alloc((size_t)L.n * 24);
+      int64_t* bt = (int64_t*)G.alloc((size_t)L.n * 8);
+      L.code = (int64_t*)G.alloc((size_t)k * L.n * 8);
+      L.order = (int64_t*)G.alloc((size_t)k * L.n * 8);
+      L.inverse = (int64_t*)G.alloc((size_t)k * L.n * 8);
+      RUNR(ptv3_pool_reduce(nullptr, nullptr, P.grid, P.batch, P.code, k, P.order, P.seg, P.n, L.n, C, pd, nullptr,
+                           nullptr, 0, perm, nullptr, nullptr, g, bt, L.code, d->dtype, sg));
+      L.grid = g; L.batch = bt;
       {
         size_t wsb = ptv3_argsort_workspace_bytes(k, L.n);
-        size_t m2 = A.off;
-        void* ws = R.alloc(wsb);
-        if (!dry && R.ok()) {
-          int r = ptv3_argsort_i64(L.code, k, L.n, std::max(1, 3 * L.depth + nbits), L.order, L.inverse, ws, wsb, s);
-          if (r) R.rc = r;
-        }
-        A.off = m2;
+        void* ws = G.alloc(wsb);
+        RUNR(ptv3_argsort_i64(L.code, k, L.n, std::max(1, 3 * L.depth + nbits), L.order, L.inverse, ws, wsb, sg));
       }
-      R.prepare_sites(L, L.grid, 1, false);
-    } else if (io->stage_points_host) {
-      io->stage_points_host[0] = L.n;
+      R.level_geometry(L, st, L.grid, 1, false);
+      if (!d->enc_mode) {
+        P.cluster32 = (int32_t*)G.alloc((size_t)P.n * 4);
+        if (!dry && R.ok())
+          hipLaunchKernelGGL(i64_to_i32_kernel, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, sg, P.cluster, P.cluster32, P.n);
+      }
+      if (!dry && R.ok()) { L.ready = event_at(1 + st); (void)hipEventRecord(L.ready, sg); }
+      // ---- features of the pooled level: proj -> segmented max + folded BN + GELU (:416-418, 439-442)
+      wait_level(L);
+      L.feat = F.alloc((size_t)L.n * C * es);
+      const size_t mark = F.off;
+      void* proj = F.alloc((size_t)P.n * C * es);
+      R.gemm(P.feat, pp.w, proj, P.n, Cp, C, 1, nullptr, nullptr, pp.b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+      RUNR(ptv3_pool_reduce(proj, nullptr, nullptr, nullptr, nullptr, k, P.order, P.seg, P.n, L.n, C, pd, pp.bns, pp.bnt,
+                           PTV3_ACT_GELU, nullptr, L.feat, nullptr, nullptr, nullptr, nullptr, d->dtype, sf));
+      F.off = mark;
+      L.conv_feat = L.feat;
     }
     for (int i = 0; i < d->enc_depths[st]; ++i)
-      R.block(L, d->enc_channels[st], d->enc_heads[st], d->enc_patch[st], i % k);
+      R.block(L, L.plan[0], d->enc_channels[st], d->enc_heads[st], i % k);
     if (!R.ok()) break;
   }
-  // ---- decoder (:651-697)
+  // ---------------- decoder (:651-697)
   if (!d->enc_mode && R.ok()) {
     for (int st = S - 2; st >= 0; --st) {
       Level& P = lv[st];
@@ -269,50 +370,47 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
       const float* bns = (const float*)R.next(); const float* bnt = (const float*)R.next();
       const void* ws_ = R.next(); const float* bs = (const float*)R.next();
       const float* bnss = (const float*)R.next(); const float* bnst = (const float*)R.next();
-      void* skip = R.alloc((size_t)P.n * Cd * es);
-      void* fused = (st == 0 && io->out_feat) ? io->out_feat : R.alloc((size_t)P.n * Cd * es);
-      int32_t* c32 = (int32_t*)R.alloc((size_t)P.n * 4);
-      const size_t mark = A.off;
-      void* up = R.alloc((size_t)Ch.n * Cd * es);
-      if (!dry && R.ok())
-        hipLaunchKernelGGL(i64_to_i32_kernel, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, s, P.cluster, c32, P.n);
+      void* skip = F.alloc((size_t)P.n * Cd * es);
+      void* fused = (st == 0 && io->out_feat) ? io->out_feat : F.alloc((size_t)P.n * Cd * es);
+      const size_t mark = F.off;
+      void* up = F.alloc((size_t)Ch.n * Cd * es);
       R.gemm(Ch.feat, w, up, Ch.n, Cin, Cd, 1, nullptr, nullptr, b, bns, bnt, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
       // skip branch; its epilogue gathers the up-branch rows by cluster id.  `skip` alone stays the sparse
       // tensor's features for the next block's conv (the reference never refreshes it after the add, :478)
-      R.gemm(P.feat, ws_, skip, P.n, Cskip, Cd, 1, nullptr, nullptr, bs, bnss, bnst, PTV3_ACT_GELU, up, c32, fused);
-      A.off = mark;
+      R.gemm(P.feat, ws_, skip, P.n, Cskip, Cd, 1, nullptr, nullptr, bs, bnss, bnst, PTV3_ACT_GELU, up, P.cluster32, fused);
+      F.off = mark;
       P.feat = fused; P.conv_feat = skip; P.channels = Cd;
       for (int i = 0; i < d->dec_depths[st]; ++i)
-        R.block(P, Cd, d->dec_heads[st], d->dec_patch[st], i % k);
+        R.block(P, P.plan[1], Cd, d->dec_heads[st], i % k);
       if (!R.ok()) break;
     }
   }
-  // ---- dense head: Linear -> folded BN -> ReLU -> Linear (offset_keypoint_ptv3.py:26-31)
+  // ---------------- dense head: Linear -> folded BN -> ReLU -> Linear (offset_keypoint_ptv3.py:26-31)
   if (R.ok() && d->head_out > 0 && !d->enc_mode) {
     Level& L = lv[0];
     const void* w0 = R.next(); const float* b0 = (const float*)R.next();
     const float* bns = (const float*)R.next(); const float* bnt = (const float*)R.next();
     const void* w1 = R.next(); const float* b1 = (const float*)R.next();
-    const size_t mark = A.off;
-    void* hid = R.alloc((size_t)L.n * d->head_hidden * es);
+    const size_t mark = F.off;
+    void* hid = F.alloc((size_t)L.n * d->head_hidden * es);
     R.gemm(L.feat, w0, hid, L.n, L.channels, d->head_hidden, 1, nullptr, nullptr, b0, bns, bnt, PTV3_ACT_RELU, nullptr,
            nullptr, nullptr);
     if (d->dtype == PTV3_F32) {
       R.gemm(hid, w1, io->out_head, L.n, d->head_hidden, d->head_out, 1, nullptr, nullptr, b1, nullptr, nullptr, 0,
              nullptr, nullptr, nullptr);
     } else {
-      void* o = R.alloc((size_t)L.n * d->head_out * es);
+      void* o = F.alloc((size_t)L.n * d->head_out * es);
       R.gemm(hid, w1, o, L.n, d->head_hidden, d->head_out, 1, nullptr, nullptr, b1, nullptr, nullptr, 0, nullptr,
              nullptr, nullptr);
-      if (!dry && R.ok()) { int r = ptv3_cast(o, PTV3_BF16, io->out_head, PTV3_F32, L.n * d->head_out, s); if (r) R.rc = r; }
+      if (!dry && R.ok()) { int r = ptv3_cast(o, PTV3_BF16, io->out_head, PTV3_F32, L.n * d->head_out, sf); if (r) R.rc = r; }
     }
-    A.off = mark;
+    F.off = mark;
   }
   if (!dry && R.ok() && !d->enc_mode && io->out_feat && lv[0].feat != io->out_feat)
-    (void)hipMemcpyAsync(io->out_feat, lv[0].feat, (size_t)lv[0].n * lv[0].channels * es, hipMemcpyDeviceToDevice, s);
-  if (peak) *peak = A.peak;
+    (void)hipMemcpyAsync(io->out_feat, lv[0].feat, (size_t)lv[0].n * lv[0].channels * es, hipMemcpyDeviceToDevice, sf);
+  if (!dry) (void)hipEventRecord(event_at(20 + (g_call & 1)), sf);  // this call's readers of its geometry arena
   if (param_count) *param_count = R.pi;
-  if (A.failed) { set_error("forward: workspace arena too small (need > %zu bytes)", A.cap); return PTV3_ERR_ARG; }
+  if (G.failed || F.failed) { set_error("forward: workspace arena too small"); return PTV3_ERR_ARG; }
   if (R.rc) return R.rc;
   if (!dry) PTV3_LAUNCH_CHECK();
   return PTV3_OK;
@@ -326,43 +424,48 @@ static int check_desc(const ptv3_model_desc* d) {
   return PTV3_OK;
 }
 
+// worst-case (nothing merges at any pooling) sizes of the two arena parts
+static void plan_bytes(const ptv3_model_desc* desc, int64_t n, int b, size_t* geo, size_t* feat, int* count) {
+  std::vector<int> ids(desc->num_orders, 0), perm((size_t)desc->num_stages * desc->num_orders, 0);
+  ptv3_forward_io io{};
+  io.n = n; io.b = b; io.depth = 0; io.order_ids_host = ids.data(); io.pool_perm_host = perm.data();
+  io.coord_is_i64 = 1;
+  Arena G{nullptr, 0, 0, 0, true, false}, F{nullptr, 0, 0, 0, true, false};
+  run_forward(desc, nullptr, &io, G, F, nullptr, true, count);
+  // slack: every scene may gain up to one window of borrowed rows per window plan
+  *geo = (G.peak + (size_t)b * 16384 * 64 + (1 << 20) + 255) / 256 * 256;
+  *feat = (F.peak + (1 << 20) + 255) / 256 * 256;
+}
+
 }  // namespace ptv3
 
 using namespace ptv3;
 
 extern "C" size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b) {
   if (check_desc(desc)) return 0;
-  std::vector<int64_t> off(b);
-  for (int i = 0; i < b; ++i) off[i] = n * (i + 1) / b;  // shape only matters through n and b
-  std::vector<int> ids(desc->num_orders, 0), perm((size_t)desc->num_stages * desc->num_orders, 0);
-  for (int st = 0; st < desc->num_stages; ++st)
-    for (int r = 0; r < desc->num_orders; ++r) perm[(size_t)st * desc->num_orders + r] = (r + 1) % desc->num_orders;
-  ptv3_forward_io io{};
-  io.n = n; io.b = b; io.depth = 16; io.offset_host = off.data(); io.order_ids_host = ids.data();
-  io.pool_perm_host = perm.data(); io.coord_is_i64 = 1;
-  Arena A{nullptr, 0, 0, 0, true, false};
-  size_t peak = 0;
-  run_forward(desc, nullptr, &io, A, nullptr, true, &peak);
-  // pad plan slack: every scene may gain up to one window of borrowed rows per attention plan
-  return peak + (size_t)b * 16384 * 64 + (1 << 20);
+  size_t g, f;
+  plan_bytes(desc, n, b, &g, &f, nullptr);
+  return 2 * g + f + 512;  // two geometry arenas (consecutive calls alternate), one feature arena
 }
 
 extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
                             const ptv3_forward_io* io, void* workspace, size_t workspace_bytes, void* stream) {
   if (int r = check_desc(desc)) return r;
   PTV3_REQUIRE(io->n >= 1 && io->b >= 1, "forward: empty batch");
-  PTV3_REQUIRE(io->depth >= 1 && io->depth <= 16, "forward: depth %d outside [1,16]", io->depth);
+  PTV3_REQUIRE(io->depth <= 16, "forward: depth %d > 16", io->depth);
   PTV3_REQUIRE(io->code && io->order && io->inverse, "forward: level-0 serialization outputs are required");
-  for (int i = 0; i < io->b; ++i)
-    PTV3_REQUIRE(io->offset_host[i] > (i ? io->offset_host[i - 1] : 0), "forward: empty scene %d", i);
-  PTV3_REQUIRE(io->offset_host[io->b - 1] == io->n, "forward: offset does not end at n");
-  {  // the flat parameter table must match the walk of run_forward exactly
-    Arena D{nullptr, 0, 0, 0, true, false};
-    int count = 0;
-    run_forward(desc, nullptr, io, D, nullptr, true, nullptr, &count);
-    PTV3_REQUIRE(count == num_params, "forward: %d parameter pointers given, the model description needs %d",
-                 num_params, count);
-  }
-  Arena A{(char*)workspace, workspace_bytes, 0, 0, false, false};
-  return run_forward(desc, params, io, A, (hipStream_t)stream, false, nullptr);
+  size_t g, f;
+  int count = 0;
+  plan_bytes(desc, io->n, io->b, &g, &f, &count);
+  PTV3_REQUIRE(count == num_params, "forward: %d parameter pointers given, the model description needs %d",
+               num_params, count);
+  PTV3_REQUIRE(workspace_bytes >= 2 * g + f + 256, "forward: workspace %zu bytes < %zu (ptv3_forward_workspace_bytes)",
+               workspace_bytes, 2 * g + f + 256);
+  char* base = (char*)workspace;
+  size_t goff = (256 - ((uintptr_t)base & 255)) & 255;
+  ++g_call;
+  event_at(21);  // make sure the two arena events exist (an unrecorded event never blocks a wait)
+  Arena G{base + goff + (g_call & 1) * g, g, 0, 0, false, false};
+  Arena F{base + goff + 2 * g, f, 0, 0, false, false};
+  return run_forward(desc, params, io, G, F, (hipStream_t)stream, false, nullptr);
 }

@@ -268,9 +268,12 @@ static int bk_of(int dtype) { return dtype == PTV3_F32 ? 32 : 64; }
 // longer per-wave epilogue and the lower workgroup count.  32-channel blocks only for narrow outputs.
 static int choose_nt(int cout) {
   static const int opts[] = {2, 4, 6, 8, 12, 16};
-  if (const char* e = getenv("PTV3_GEMM_NT")) {  // tuning override (tools/bench_gemm.py)
-    int v = atoi(e);
-    for (int nt : opts) if (nt == v) return v;
+  static const bool tuning = getenv("PTV3_GEMM_TUNE") != nullptr;  // tools/bench_gemm.py only
+  if (tuning) {
+    if (const char* e = getenv("PTV3_GEMM_NT")) {
+      int v = atoi(e);
+      for (int nt : opts) if (nt == v) return v;
+    }
   }
   return cout <= 32 ? 2 : 4;
 }

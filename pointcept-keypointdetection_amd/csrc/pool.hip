@@ -242,12 +242,17 @@ extern "C" int ptv3_pool_reduce(const void* feat, const float* coord, const int6
   PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "pool_reduce: bad dtype");
   if (n_out == 0) return PTV3_OK;
   hipStream_t s = (hipStream_t)stream;
-  int rc = dtype == PTV3_F32
-               ? launch_pool_feat<float>(feat, order0, seg_start, n_out, c, bn_scale, bn_shift, act, feat_out, s)
-               : launch_pool_feat<__bf16>(feat, order0, seg_start, n_out, c, bn_scale, bn_shift, act, feat_out, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(pool_meta_kernel, dim3((unsigned)cdiv(n_out, 256)), dim3(256), 0, s, coord, grid_coord, batch,
-                     code, k, order0, seg_start, n, n_out, pooling_depth, perm, coord_out, grid_out, batch_out, code_out);
+  if (feat != nullptr) {  // feature half (segmented max + folded BN + act)
+    int rc = dtype == PTV3_F32
+                 ? launch_pool_feat<float>(feat, order0, seg_start, n_out, c, bn_scale, bn_shift, act, feat_out, s)
+                 : launch_pool_feat<__bf16>(feat, order0, seg_start, n_out, c, bn_scale, bn_shift, act, feat_out, s);
+    if (rc) return rc;
+  }
+  if (grid_coord != nullptr) {  // geometry half (coord mean, head gathers, pooled codes)
+    hipLaunchKernelGGL(pool_meta_kernel, dim3((unsigned)cdiv(n_out, 256)), dim3(256), 0, s, coord, grid_coord, batch,
+                       code, k, order0, seg_start, n, n_out, pooling_depth, perm, coord_out, grid_out, batch_out,
+                       code_out);
+  }
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -469,6 +469,10 @@ class PointTransformerV3(PointModule):
         # True: one ptv3_forward call per forward (native executor) whenever the tree is the standard eval
         # configuration and no forward hooks are attached; False: module-by-module (same kernels, same results)
         self.use_engine = True
+        # True: the caller guarantees grid_coord / batch / offset were materialised before the call (not
+        # produced on the current stream just now); consecutive forwards then pipeline (geometry of call i+1
+        # under the feature tail of call i).  Default False = fully stream-ordered.
+        self.inputs_resident = False
 
         assert self.num_stages == len(stride) + 1
         assert self.num_stages == len(enc_depths)
@@ -546,13 +550,20 @@ class PointTransformerV3(PointModule):
     def forward(self, data_dict, _head=None):
         _no_training(self)
         with torch.no_grad():
+            use_engine = self.use_engine and _engine.eligible(self, _head)
+            if use_engine and "batch" not in data_dict and "offset" in data_dict and not isinstance(data_dict, Point):
+                # the executor derives the batch ids on its geometry stream: hand it an uninitialised buffer
+                data_dict = dict(data_dict)
+                data_dict["batch"] = torch.empty(data_dict["feat"].shape[0], dtype=torch.long,
+                                                 device=data_dict["feat"].device)
+                data_dict["_batch_pending"] = True
             point = Point(data_dict)
             dtype = self.resolve_dtype()
             feat = point.feat
             if feat.dtype not in (torch.float32, torch.bfloat16):
                 feat = feat.float()
             point.feat = ops.cast(feat.contiguous(), dtype)
-            if self.use_engine and _engine.eligible(self, _head):
+            if use_engine:
                 point._ensure_grid_coord()
                 point, head_out = _engine.forward(self, point, dtype, _head)
                 if _head is not None:

@@ -4,7 +4,9 @@ import torch
 
 @torch.no_grad()
 def offset2bincount(offset):
-    return torch.diff(offset, prepend=torch.tensor([0], device=offset.device, dtype=torch.long))
+    # new_zeros instead of the reference's torch.tensor([0], device=...): a host list -> device copy is a
+    # blocking transfer on the current stream, i.e. a hidden pipeline drain in front of every forward
+    return torch.diff(offset, prepend=offset.new_zeros(1))
 
 
 @torch.no_grad()
@@ -13,9 +15,14 @@ def bincount2offset(bincount):
 
 
 @torch.no_grad()
-def offset2batch(offset):
+def offset2batch(offset, num_points=None):
+    """num_points (= offset[-1], known from any per-point tensor) avoids the device->host read that
+    repeat_interleave otherwise needs to size its output."""
     bincount = offset2bincount(offset)
-    return torch.arange(len(bincount), device=offset.device, dtype=torch.long).repeat_interleave(bincount)
+    ids = torch.arange(len(bincount), device=offset.device, dtype=torch.long)
+    if num_points is not None:
+        return ids.repeat_interleave(bincount, output_size=int(num_points))
+    return ids.repeat_interleave(bincount)
 
 
 @torch.no_grad()

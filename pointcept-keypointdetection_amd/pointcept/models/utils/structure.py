@@ -34,7 +34,12 @@ class Point(AttrDict):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         if "batch" not in self.keys() and "offset" in self.keys():
-            self["batch"] = offset2batch(self.offset)
+            n = None
+            for key in ("feat", "coord", "grid_coord"):
+                if key in self.keys() and torch.is_tensor(self[key]):
+                    n = self[key].shape[0]
+                    break
+            self["batch"] = offset2batch(self.offset, n)
         elif "offset" not in self.keys() and "batch" in self.keys():
             self["offset"] = batch2offset(self.batch)
 

@@ -23,7 +23,8 @@ class ForwardIO(ctypes.Structure):
                 ("offset", c_void_p), ("offset_host", POINTER(c_int64)), ("b", c_int32), ("n", c_int64),
                 ("depth", c_int32), ("order_ids_host", POINTER(c_int32)), ("pool_perm_host", POINTER(c_int32)),
                 ("code", c_void_p), ("order", c_void_p), ("inverse", c_void_p), ("out_feat", c_void_p),
-                ("out_head", c_void_p), ("stage_points_host", POINTER(c_int64))]
+                ("out_head", c_void_p), ("stage_points_host", POINTER(c_int64)), ("depth_out", POINTER(c_int32)),
+                ("batch_out", c_void_p), ("inputs_resident", c_int32)]
 
 
 def declare(dll):
@@ -56,7 +57,7 @@ class Packed:
         self.tensors = None
 
     def fresh(self):
-        v = [(t.data_ptr(), t._version) for t in self.sources]
+        v = [t._version for t in self.sources]
         if v != self.versions:
             with torch.no_grad():
                 self.tensors = self._pack()
@@ -192,7 +193,9 @@ def forward(backbone, point, dtype, head=None):
     if key not in cache:
         cache[key] = Packed(backbone, head, dtype)
     pk = cache[key].fresh()
-    desc = _desc(backbone, head, dtype, pk.cin_pad)
+    if getattr(pk, "desc", None) is None:
+        pk.desc = _desc(backbone, head, dtype, pk.cin_pad)
+    desc = pk.desc
 
     k = len(backbone.order)
     S = backbone.num_stages
@@ -214,13 +217,11 @@ def forward(backbone, point, dtype, head=None):
     if gc.dtype not in (torch.int32, torch.int64):
         gc = gc.long()
     gc = gc.contiguous()
-    batch = point.batch.long().contiguous()
     offset = point.offset.long().contiguous()
-    off_host = point.offset_host()
-    nb = len(off_host)
-    depth = int(max(point.grid_max_host()) + 1).bit_length()
-    assert depth * 3 + nb.bit_length() <= 63 and depth <= 16
-    dev = feat.device
+    derive_batch = point.get("_batch_pending", False)
+    batch = point.batch if derive_batch else point.batch.long().contiguous()
+    nb = int(offset.shape[0])   # scene offsets and the coordinate maximum are read back by the executor on its
+    dev = feat.device           # geometry stream: no synchronisation of the caller's stream here
     code = torch.empty((k, n), dtype=torch.int64, device=dev)
     order = torch.empty_like(code)
     inverse = torch.empty_like(code)
@@ -234,9 +235,16 @@ def forward(backbone, point, dtype, head=None):
     stage_pts = (c_int64 * 8)()
     io = ForwardIO()
     io.grid_coord, io.coord_is_i64 = gc.data_ptr(), int(gc.dtype == torch.int64)
-    io.feat, io.batch, io.offset = feat.data_ptr(), batch.data_ptr(), offset.data_ptr()
-    off_arr = (c_int64 * nb)(*off_host)
-    io.offset_host, io.b, io.n, io.depth = off_arr, nb, n, depth
+    io.feat, io.offset = feat.data_ptr(), offset.data_ptr()
+    if derive_batch:   # the executor fills point.batch itself (geometry stream)
+        io.batch, io.batch_out = None, batch.data_ptr()
+        del point["_batch_pending"]
+    else:
+        io.batch, io.batch_out = batch.data_ptr(), None
+    depth_out = c_int32(0)
+    io.offset_host, io.b, io.n, io.depth = None, nb, n, 0
+    io.depth_out = ctypes.pointer(depth_out)
+    io.inputs_resident = int(bool(getattr(backbone, "inputs_resident", False)))
     io.order_ids_host, io.pool_perm_host = order_ids, perm_arr
     io.code, io.order, io.inverse = code.data_ptr(), order.data_ptr(), inverse.data_ptr()
     io.out_feat = out_feat.data_ptr()
@@ -245,6 +253,8 @@ def forward(backbone, point, dtype, head=None):
     rc = dll.ptv3_forward(ctypes.byref(desc), pk.table, len(pk.tensors), ctypes.byref(io), arena.data_ptr(),
                           arena.numel(), ops._stream())
     lib.check(rc, "ptv3_forward")
+    depth = int(depth_out.value)
+    assert depth * 3 + nb.bit_length() <= 63
     point["order"] = list(backbone.order)
     point["serialized_depth"] = depth
     point["serialized_code"], point["serialized_order"], point["serialized_inverse"] = code, order, inverse

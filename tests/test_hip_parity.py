@@ -403,6 +403,34 @@ def test_native_executor_matches_module_path_and_golden(dev, golden_dir):
     assert np.array_equal(pt.serialized_order.cpu().numpy(), g["tap_serialized_order"])
 
 
+def test_pipelined_calls_match_serial(dev):
+    """inputs_resident=True lets the geometry of call i+1 run under the feature tail of call i (two geometry
+    arenas, events between the two streams).  Back-to-back calls on different scenes, no synchronisation in
+    between, must give exactly the serial results."""
+    import ptv3_scenes as S
+    torch.manual_seed(3)
+    model = _build(TINY_CFG, hidden_dim=32).to(dev).eval()
+    scenes = [{k: v.to(dev) for k, v in S.make_batch(sz, in_channels=4, extent=64, seed=40 + i).items()}
+              for i, sz in enumerate([[4000, 2500], [3000], [5000, 1000, 800], [2500, 2500], [6000]])]
+    torch.cuda.synchronize()
+    serial = []
+    for sc in scenes:
+        torch.manual_seed(9)
+        with torch.no_grad():
+            serial.append(model(sc)["pred"].clone())
+        torch.cuda.synchronize()
+    model.backbone.inputs_resident = True
+    outs = []
+    for rep in range(3):
+        for sc in scenes:
+            torch.manual_seed(9)
+            with torch.no_grad():
+                outs.append(model(sc)["pred"])
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, serial[i % len(scenes)]), i
+
+
 @pytest.mark.parametrize("sizes,kind,extent", [([12000, 9000], "surface", 128), ([15000], "lidar", 1024)])
 def test_fork_config_vs_oracle(dev, sizes, kind, extent):
     """configs/my_dataset/offset_keypoint_ptv3.py shape (46M parameters) - HIP model against the oracle

@@ -2,6 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pointcept-keypointdetection_amd"))
+os.environ["PTV3_GEMM_TUNE"] = "1"
 import torch
 from ptv3_hip import ops
 dev = torch.device("cuda:0")
