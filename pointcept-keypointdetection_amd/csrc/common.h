@@ -41,8 +41,15 @@ __device__ __forceinline__ float bf16_to_f32(short s) {
 
 template <typename T> __device__ __forceinline__ typename Vec4<T>::type pack4(float a, float b, float c, float d);
 template <> __device__ __forceinline__ f32x4 pack4<float>(float a, float b, float c, float d) { return f32x4{a, b, c, d}; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <> __device__ __forceinline__ s16x4 pack4<__bf16>(float a, float b, float c, float d) {
-  return s16x4{bf16_bits(a), bf16_bits(b), bf16_bits(c), bf16_bits(d)};
+  // two v_cvt_pk_bf16_f32 (vector conversion), not four scalar converts + permutes
+  bf16x2 lo = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  bf16x2 hi = __builtin_convertvector(f32x2{c, d}, bf16x2);
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 w = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+  return __builtin_bit_cast(s16x4, w);
 }
 template <typename T> __device__ __forceinline__ void unpack4(typename Vec4<T>::type v, float* o);
 template <> __device__ __forceinline__ void unpack4<float>(f32x4 v, float* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }

@@ -12,6 +12,9 @@
 // Mirrors point_transformer_v3m1_base.py:699-714 -> structure.py:52-146, Embedding :485-515,
 // Block :318-338, SerializedPooling :371-444, SerializedUnpooling :471-482 in eval mode.
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include <vector>
 #include "common.h"
 #include "../../include/ptv3_hip.h"
@@ -98,6 +101,16 @@ struct Level {
 static hipStream_t g_geo_stream = nullptr;
 static std::vector<hipEvent_t> g_events;
 static unsigned g_call = 0;  // calls alternate between the two geometry arenas (see ptv3_forward)
+static double g_sync_us = 0.0;  // host time blocked in geometry-stream read-backs (PTV3_ENGINE_TIMING=1)
+static inline double now_us() {
+  return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static hipError_t timed_sync(hipStream_t s) {
+  double t = now_us();
+  hipError_t e = hipStreamSynchronize(s);
+  g_sync_us += now_us() - t;
+  return e;
+}
 
 static hipEvent_t event_at(size_t i) {
   while (g_events.size() <= i) {
@@ -214,9 +227,15 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
   R.es = d->dtype == PTV3_F32 ? 4 : 2;
   const int S = d->num_stages, k = d->num_orders, es = R.es;
   if (!dry) {
-    if (!g_geo_stream && hipStreamCreateWithFlags(&g_geo_stream, hipStreamNonBlocking) != hipSuccess) {
-      set_error("forward: cannot create the geometry stream");
-      return PTV3_ERR_LAUNCH;
+    if (!g_geo_stream) {
+      // highest priority: the geometry chain is a string of tiny dependent kernels whose read-backs gate the
+      // host; its workgroups must not queue behind the long feature kernels of the other stream
+      int least = 0, greatest = 0;
+      (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+      if (hipStreamCreateWithPriority(&g_geo_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+        set_error("forward: cannot create the geometry stream");
+        return PTV3_ERR_LAUNCH;
+      }
     }
     if (!io->inputs_resident) {
       // coordinates / offsets may have been produced on the caller's stream just before this call
@@ -256,7 +275,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
     if (io->offset_host) std::copy(io->offset_host, io->offset_host + io->b, L0.off_host.begin());
     else (void)hipMemcpyAsync(L0.off_host.data(), io->offset, (size_t)io->b * 8, hipMemcpyDeviceToHost, sg);
     if (dmax || !io->offset_host) {
-      if (hipStreamSynchronize(sg) != hipSuccess) { set_error("forward: input read-back failed"); return PTV3_ERR_LAUNCH; }
+      if (timed_sync(sg) != hipSuccess) { set_error("forward: input read-back failed"); return PTV3_ERR_LAUNCH; }
     }
     if (dmax) { depth = 0; for (unsigned v = (unsigned)hmax + 1; v; v >>= 1) ++depth; }
     PTV3_REQUIRE(depth >= 1 && depth <= 16, "forward: serialization depth %d outside [1,16] (structure.py:81)", depth);
@@ -318,7 +337,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
         L.off_host = P.off_host;  // worst case: nothing merges
       } else if (R.ok()) {
         if (hipMemcpyAsync(L.off_host.data(), poff, (size_t)io->b * 8, hipMemcpyDeviceToHost, sg) != hipSuccess ||
-            hipStreamSynchronize(sg) != hipSuccess) { set_error("forward: offset read-back failed"); return PTV3_ERR_LAUNCH; }
+            timed_sync(sg) != hipSuccess) { set_error("forward: offset read-back failed"); return PTV3_ERR_LAUNCH; }
       }
       if (!R.ok()) break;
       L.n = L.off_host[io->b - 1]; L.depth = P.depth - pd; L.offset = poff; L.channels = C;
@@ -464,8 +483,14 @@ extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* para
   char* base = (char*)workspace;
   size_t goff = (256 - ((uintptr_t)base & 255)) & 255;
   ++g_call;
+  static const bool timing = getenv("PTV3_ENGINE_TIMING") != nullptr;
+  const double t_begin = timing ? now_us() : 0.0;
+  g_sync_us = 0.0;
   event_at(21);  // make sure the two arena events exist (an unrecorded event never blocks a wait)
   Arena G{base + goff + (g_call & 1) * g, g, 0, 0, false, false};
   Arena F{base + goff + 2 * g, f, 0, 0, false, false};
-  return run_forward(desc, params, io, G, F, (hipStream_t)stream, false, nullptr);
+  int rc = run_forward(desc, params, io, G, F, (hipStream_t)stream, false, nullptr);
+  if (timing)
+    fprintf(stderr, "[ptv3_forward] host %.0f us total, %.0f us blocked in read-backs\n", now_us() - t_begin, g_sync_us);
+  return rc;
 }

@@ -5,6 +5,7 @@
 // lane, keys in the 4 acc registers x 4 lane groups; that accumulator is directly the B operand
 // of O^T += V^T * P^T, so P never touches LDS.
 // Reference semantics: SerializedAttention.forward, point_transformer_v3m1_base.py:184-216.
+#include <type_traits>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
@@ -232,11 +233,27 @@ __device__ __forceinline__ float lanes_sum_groups(float x) {
   return x + __shfl_xor(x, 32, 64);
 }
 
+// fmaxf(fmaxf(a, b), c) lowers to v_max3_f32 (an asm form reading MFMA results directly would need its own
+// hazard padding: the compiler does not pad inside asm statements)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 template <typename T> struct WaFull {
   static constexpr int VPAD = sizeof(T) == 2 ? 8 : 4;  // V^T row padding (elements): conflict-free fragment reads
 };
 
-template <typename T, int ND>
+// row sums of P: bf16 puts them on the matrix core (A = all-ones tile: every row of the product is the
+// column sum of P^T, already summed over the 4 lane groups), fp32 keeps lane-partial VALU sums
+template <typename T> struct RowSum;
+template <> struct RowSum<__bf16> {
+  static constexpr bool kOnMfma = true;
+  static __device__ __forceinline__ s16x4 ones() { return s16x4{0x3F80, 0x3F80, 0x3F80, 0x3F80}; }
+};
+template <> struct RowSum<float> {
+  static constexpr bool kOnMfma = false;
+  static __device__ __forceinline__ f32x4 ones() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
+};
+
+template <typename T, int ND, bool RPE>
 __global__ void __launch_bounds__(512)
 window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
                         const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
@@ -245,6 +262,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
   constexpr int KS = D + 4;
+  constexpr bool SUM_MFMA = RowSum<T>::kOnMfma;
   const int VS = Kpad + WaFull<T>::VPAD;
   const int nthreads = blockDim.x;
   const int QB = (nthreads >> 6) * QT * 16;  // queries per workgroup
@@ -323,18 +341,20 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   __syncthreads();
   if (!__any(any_q)) return;  // whole wave past the window end: nothing left to synchronise with
 
-  f32x4 o[QT][ND];
-  float m[QT], l[QT];
+  // softmax state per query tile.  negm = -(running reference max) is the INITIAL ACCUMULATOR of the score
+  // product, so the matrix core hands back (score - max) and no subtraction is issued per score.
+  f32x4 o[QT][ND], negm[QT], lacc[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    m[t] = -INFINITY;
-    l[t] = 0.f;
+    negm[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    lacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < ND; ++c) o[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  const V4 ones = RowSum<T>::ones();
 
-  const int ntiles = Kpad / WA_KT;
-  for (int tile = 0; tile < ntiles; ++tile) {
+  auto tile_body = [&](const int tile, auto mask_tag) {
+    constexpr bool MASK = decltype(mask_tag)::value;
     const int key0 = tile * WA_KT;
     V4 kf[4][ND], vf[ND][4];
 #pragma unroll
@@ -344,69 +364,91 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
         kf[kt][c] = *reinterpret_cast<const V4*>(sK + (size_t)(key0 + 16 * kt + li) * KS + 16 * c + 4 * g);
         vf[c][kt] = *reinterpret_cast<const V4*>(sV + (size_t)(16 * c + li) * VS + key0 + 16 * kt + 4 * g);
       }
-    const bool tail = key0 + WA_KT > K;
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-      f32x4 s[4];
+      f32x4 s[4];  // score - reference max, log2 domain
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = negm[t];
 #pragma unroll
         for (int c = 0; c < ND; ++c) acc = mma16<T>(kf[kt][c], qf[t][c], acc);
         s[kt] = acc;
       }
-      if (rpe != nullptr && qidx[t] < K) {
-        const float* rb = rpe + (((int64_t)w * H + h) * K + qidx[t]) * K;
+      if constexpr (RPE) {
+        if (qidx[t] < K) {
+          const float* rb = rpe + (((int64_t)w * H + h) * K + qidx[t]) * K;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+          for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            int key = key0 + 16 * kt + 4 * g + r;
-            if (key < K) s[kt][r] += rb[key] * 1.44269504088896340736f;
-          }
+            for (int r = 0; r < 4; ++r) {
+              int key = key0 + 16 * kt + 4 * g + r;
+              if (key < K) s[kt][r] += rb[key] * 1.44269504088896340736f;
+            }
+        }
       }
-      if (tail) {
+      if constexpr (MASK) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (key0 + 16 * kt + 4 * g + r >= K) s[kt][r] = -INFINITY;
       }
-      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])),
-                       fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])),
-                           fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
-      if (__any(mx > m[t] + WA_RESCALE_THR)) {  // wave-uniform; rare after the first tiles
-        const float mn = fmaxf(m[t], lanes_max_groups(mx));
-        const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);
-        m[t] = mn;
-        l[t] *= alpha;
+      // 16 values -> 8 x v_max3_f32
+      float mx = max3_raw(s[0][0], s[0][1], s[0][2]);
+      mx = max3_raw(mx, s[0][3], s[1][0]);
+      mx = max3_raw(mx, s[1][1], s[1][2]);
+      mx = max3_raw(mx, s[1][3], s[2][0]);
+      mx = max3_raw(mx, s[2][1], s[2][2]);
+      mx = max3_raw(mx, s[2][3], s[3][0]);
+      mx = max3_raw(mx, s[3][1], s[3][2]);
+      mx = fmaxf(mx, s[3][3]);
+      // Lazy rescale (wave-uniform): the first tile pins the reference to its row maximum; afterwards the
+      // exchange + rescale only run when some row maximum outgrew the reference by more than 2^THR.
+      if (__builtin_expect(tile == 0 || __any(mx > WA_RESCALE_THR), 0)) {
+        float d = lanes_max_groups(mx);      // new max - old reference (same for the 4 lanes of a query)
+        if (tile > 0) d = fmaxf(d, 0.f);     // the reference never moves down after the first tile
+        if (tile > 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          lacc[t] *= alpha;
 #pragma unroll
-        for (int c = 0; c < ND; ++c) o[t][c] *= alpha;
+          for (int c = 0; c < ND; ++c) o[t][c] *= alpha;
+        }
+        negm[t] -= d;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] -= d;
       }
-      const float mt = m[t];
       float ps = 0.f;
       V4 pf[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        float p0 = __builtin_amdgcn_exp2f(s[kt][0] - mt);
-        float p1 = __builtin_amdgcn_exp2f(s[kt][1] - mt);
-        float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mt);
-        float p3 = __builtin_amdgcn_exp2f(s[kt][3] - mt);
-        ps += (p0 + p1) + (p2 + p3);
+        const float p0 = __builtin_amdgcn_exp2f(s[kt][0]);
+        const float p1 = __builtin_amdgcn_exp2f(s[kt][1]);
+        const float p2 = __builtin_amdgcn_exp2f(s[kt][2]);
+        const float p3 = __builtin_amdgcn_exp2f(s[kt][3]);
+        if constexpr (!SUM_MFMA) ps += (p0 + p1) + (p2 + p3);
         pf[kt] = pack4<T>(p0, p1, p2, p3);
       }
-      l[t] += ps;
+      if constexpr (SUM_MFMA) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) lacc[t] = mma16<T>(ones, pf[kt], lacc[t]);
+      } else {
+        lacc[t][0] += ps;
+      }
 #pragma unroll
       for (int c = 0; c < ND; ++c)
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) o[t][c] = mma16<T>(vf[c][kt], pf[kt], o[t][c]);
     }
-  }
+  };
+
+  const int full_tiles = K / WA_KT;
+  for (int tile = 0; tile < full_tiles; ++tile) tile_body(tile, std::false_type{});
+  if (full_tiles * WA_KT < K) tile_body(full_tiles, std::true_type{});
 
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
-    const float inv = 1.0f / lanes_sum_groups(l[t]);
+    const float lsum = SUM_MFMA ? lacc[t][0] : lanes_sum_groups(lacc[t][0]);
+    const float inv = 1.0f / lsum;
     if (qidx[t] < K) {
       const int row = sOrd[qidx[t]];
       if (win_inverse[row] == (int32_t)(wbase + qidx[t])) {
@@ -419,7 +461,6 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
     }
   }
 }
-
 
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
@@ -437,13 +478,21 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
     const int QB = waves * QT * 16;
     const int qsplit = (K + QB - 1) / QB;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
     const unsigned nwg = (unsigned)nwin * H * qsplit;
-    hipLaunchKernelGGL((window_attn_full_kernel<T, ND>), dim3(nwg), dim3(waves * 64), lds_full, s, (const T*)qkv, wo,
-                       wi, (T*)out, C, H, K, Kpad, nwin, qsplit, scale * 1.44269504088896340736f, rpe);
+    if (rpe)
+      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, true>), dim3(nwg), dim3(waves * 64), lds_full, s,
+                         (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
+                         scale * 1.44269504088896340736f, rpe);
+    else
+      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, false>), dim3(nwg), dim3(waves * 64), lds_full, s,
+                         (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
+                         scale * 1.44269504088896340736f, rpe);
     PTV3_LAUNCH_CHECK();
     return PTV3_OK;
   }
