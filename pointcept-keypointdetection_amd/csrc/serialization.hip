@@ -88,19 +88,19 @@ radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift, uint3
     if (i < n) atomicAdd(&h[(k[i] >> shift) & 255], 1u);
   }
   __syncthreads();
-  // digit-major so that one exclusive scan over (256 * nblk) gives every (digit, block) base
-  hist[((int64_t)row * 256 + threadIdx.x) * nblk + blockIdx.x] = h[threadIdx.x];
+  // block-major [row][block][digit]: coalesced here, in the scan and in the scatter
+  hist[((int64_t)row * nblk + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
-// one 256-thread block per row: exclusive scan of the digit-major (256 x nblk) counters.
+// one 256-thread block per row: exclusive scan, in (digit, block) order, of the [block][digit] counters.
 // thread d owns digit d: sums its nblk block counters, the 256 digit totals are scanned across the block,
 // then the thread rewrites its counters as running bases.
 __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk) {
   __shared__ uint32_t wsum[4];
-  uint32_t* h = hist + ((int64_t)blockIdx.x * 256 + threadIdx.x) * nblk;
+  uint32_t* h = hist + (int64_t)blockIdx.x * nblk * 256 + threadIdx.x;  // stride 256 between blocks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t total = 0;
-  for (int b = 0; b < nblk; ++b) total += h[b];
+  for (int b = 0; b < nblk; ++b) total += h[(int64_t)b * 256];
   uint32_t x = total;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
   uint32_t base = x - total;
   for (int w = 0; w < wave; ++w) base += wsum[w];
   for (int b = 0; b < nblk; ++b) {
-    uint32_t c = h[b];
-    h[b] = base;
+    uint32_t c = h[(int64_t)b * 256];
+    h[(int64_t)b * 256] = base;
     base += c;
   }
 }
@@ -172,13 +172,13 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __res
     }
   }
   __syncthreads();
-  const uint32_t* hrow = hist + (int64_t)row * 256 * nblk;
+  const uint32_t* hrow = hist + ((int64_t)row * nblk + blockIdx.x) * 256;
 #pragma unroll
   for (int r = 0; r < RS_ITEMS; ++r) {
     int64_t i = wbase + r * 64 + lane;
     if (i < n) {
       uint32_t d = (uint32_t)((key[r] >> shift) & 255);
-      int64_t pos = (int64_t)hrow[(int64_t)d * nblk + blockIdx.x] + cnt[wave][d] + rank[r];
+      int64_t pos = (int64_t)hrow[d] + cnt[wave][d] + rank[r];
       uint32_t v = FIRST ? (uint32_t)i : vals_in[(int64_t)row * n + i];
       if (LAST) {
         order[(int64_t)row * n + pos] = (int64_t)v;
