@@ -41,6 +41,28 @@ def reduce_over_ranks(value, device, op):
     return float(t.item())
 
 
+def pmc_traffic(args, kernel_family):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/measure_round.sh ->
+    profiles/<round>/pmc_traffic.json), if they were taken on this workload.  linear and subm_conv are the
+    same kernel (gemm_kernel), so the PMC figure covers both families."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
+    if not files:
+        return None, None
+    data = json.load(open(files[-1]))
+    w = data.get("workload", {})
+    if (w.get("points"), w.get("scenes"), w.get("dtype"), w.get("kind")) != (args.points, args.scenes, args.dtype, args.kind):
+        return None, None
+    key = {"linear": "gemm_kernel<bf16,64ch>", "subm_conv": "gemm_kernel<bf16,64ch>",
+           "window_attn": "window_attn_full_kernel"}.get(kernel_family)
+    k = data["kernels"].get(key)
+    if not k:
+        return None, None
+    return k["hbm_bytes_per_launch"], {"source": os.path.relpath(files[-1], ROOT), "kernel": key,
+                                       "hbm_mb_per_step": round(k["hbm_bytes_per_step"] / 1e6, 1),
+                                       "launches_per_step": k["launches_per_step"]}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +209,7 @@ def main():
                     "peak": PEAK_HBM if hbm_bound else PEAK[args.dtype],
                     "unit": "GB/s" if hbm_bound else "TFLOP/s",
                     "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[args.dtype]), 5),
-                    "traffic": None,
+                    "traffic": None, "traffic_detail": None,
                     "intensity_flop_per_byte": round(intensity, 1),
                     "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
                     "launches_per_step": d["launches"] // args.steps,
@@ -197,6 +219,8 @@ def main():
                     "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()},
                     "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()}}
 
+    if roofline is not None and rank == 0:
+        roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(args, roofline["kernel"])
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
