@@ -113,10 +113,30 @@ int ptv3_subm_neighbors(const int32_t* indices, int64_t n, const void* table, in
  * workspace (optional): ptv3_gemm_workspace_bytes(...) bytes of split-K slab room; shapes with few
  * rows and a long K (deep-stage convolutions) are then split over K and summed in slab order. */
 size_t ptv3_gemm_workspace_bytes(int64_t m, int cin, int cout, int kvol, int dtype);
+/* number of K slabs the shape is split into (1 = single pass).  With out == NULL ptv3_gemm leaves the raw fp32
+ * slabs [splits][m][cout] in `workspace` for a fused consumer (ptv3_block_head). */
+int ptv3_gemm_splits(int64_t m, int cin, int cout, int kvol, int dtype);
 int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int cin, int cout, int kvol,
               const int32_t* nbr, const int32_t* row_order, const float* bias, const float* bn_scale,
               const float* bn_shift, int act, const void* res, const int32_t* res_index, void* out2,
               int dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- fused row-local halves of Block.forward (point_transformer_v3m1_base.py:318-338) ----------------
+ * One wave carries 16 points through the whole chain in registers (no LDS, no barrier); available for
+ * c in {32,64} and hidden % 64 == 0 (ptv3_block_fusable: the large-M levels), wider blocks use the entry
+ * points above (small M: parallelism must come from the output-channel dimension).
+ * bf16: wqkv, w1 (input dim c) and w2 (input dim hidden) must have their input channels permuted inside every
+ * 32-chunk as [0-3,16-19,4-7,20-23,8-11,24-27,12-15,28-31] (see csrc/block_fused.hip); fp32: natural order.
+ *   head: x = conv output (or sum of its split-K slabs + conv_bias);
+ *         f1 = LN(x; g0,b0) + shortcut;  qkv = LN(f1; g1,b1) @ wqkv^T + bqkv               (:319-324, :188)
+ *   tail: f2 = attn @ wproj^T + bproj + f1;  out = f2 + fc2(GELU(fc1(LN(f2; g2,b2))))       (:219, :326-334) */
+int ptv3_block_fusable(int c, int hidden);
+int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias, const void* shortcut,
+                    const float* g0, const float* b0, const float* g1, const float* b1, const void* wqkv,
+                    const float* bqkv, void* f1, void* qkv, int64_t m, int c, float eps, int dtype, void* stream);
+int ptv3_block_tail(const void* attn, const void* f1, const void* wproj, const float* bproj, const float* g2,
+                    const float* b2, const void* w1, const float* bias1, const void* w2, const float* bias2,
+                    void* out, int64_t m, int c, int hidden, float eps, int dtype, void* stream);
 
 /* ---- normalisation / elementwise -------------------------------------------------------------
  * torch.nn.LayerNorm over the last dim (Block.cpe[2], norm1, norm2; :277-304): y = LN(x)*g+b [+ res];

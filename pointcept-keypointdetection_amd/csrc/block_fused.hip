@@ -1,0 +1,318 @@
+// Row-local halves of Block.forward fused around the two non-local ops (sparse conv, window attention):
+//
+//   block_head:  x = conv output (or the sum of its split-K slabs + bias)
+//                f1 = LayerNorm_cpe(x) + shortcut ; qkv = Linear_qkv(LayerNorm_1(f1))          (:319-324, 188)
+//   block_tail:  f2 = Linear_proj(attn) + f1 ; out = f2 + fc2(GELU(fc1(LayerNorm_2(f2))))       (:219, 326-334)
+//
+// One wave owns 16 points end to end; there is no LDS and no barrier.  GEMMs are chained in registers:
+// with the product computed as W_tile * X^T a lane holds 4 consecutive channels of ONE point per 16-channel
+// tile, and two such accumulator tiles, packed to bf16, ARE the 8-element B fragment of the next
+// v_mfma_f32_16x16x32_bf16 -- provided the next weight matrix has its input channels permuted inside every
+// 32-chunk as [0-3,16-19,4-7,20-23,8-11,24-27,12-15,28-31] (done once per weight version on the host;
+// fp32 uses 16-wide chunks where the order is the identity).  LayerNorm statistics are an in-lane sum plus
+// two cross-lane-group exchanges.  Weight fragments stream from L2 straight into registers.
+// Used for C in {32, 64}: there M is large and the chain is bandwidth/launch bound (measured at 100k points,
+// C=64: head 30 us vs 37 us unfused, tail 49 us vs 75 us).  At C >= 128 the levels are small (M ~ 10^2..10^3
+// rows): a wave would walk > 10^3 dependent weight-fragment loads alone and parallelism has to come from the
+// output-channel dimension instead, i.e. from the tiled GEMM kernel (measured C=256, M=1388: 299 us fused vs
+// 40 us unfused), so wider blocks keep the unfused kernels.
+#include "common.h"
+#include "profile.h"
+#include "../../include/ptv3_hip.h"
+
+namespace ptv3 {
+
+struct HeadArgs {
+  const void* x; const float* slab; int splits; const float* conv_bias;  // x XOR slab
+  const void* shortcut;
+  const float *g0, *b0, *g1, *b1;
+  const void* wqkv; const float* bqkv;
+  void* f1; void* qkv;
+  int64_t m; float eps;
+};
+
+struct TailArgs {
+  const void* attn; const void* f1;
+  const void* wproj; const float* bproj;
+  const float *g2, *b2;
+  const void* w1; const float* bias1; const void* w2; const float* bias2;
+  void* out;
+  int64_t m; int hidden; float eps;
+};
+
+__device__ __forceinline__ float groups_sum(float x) {
+  x += __shfl_xor(x, 16, 64);
+  return x + __shfl_xor(x, 32, 64);
+}
+
+// the B fragment of K-chunk `kc` from accumulator-layout tiles t[] (already rounded to T)
+template <typename T, int NT> struct ChainFrag;
+template <int NT> struct ChainFrag<float, NT> {
+  static constexpr int NKC = NT;  // 16-channel chunks
+  static __device__ __forceinline__ f32x4 get(const f32x4* t, int kc) { return t[kc]; }
+};
+template <int NT> struct ChainFrag<__bf16, NT> {
+  static constexpr int NKC = NT / 2;  // 32-channel chunks = two tiles
+  static __device__ __forceinline__ s16x8 get(const f32x4* t, int kc) {
+    s16x4 lo = pack4<__bf16>(t[2 * kc][0], t[2 * kc][1], t[2 * kc][2], t[2 * kc][3]);
+    s16x4 hi = pack4<__bf16>(t[2 * kc + 1][0], t[2 * kc + 1][1], t[2 * kc + 1][2], t[2 * kc + 1][3]);
+    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  }
+};
+
+template <typename T> __device__ __forceinline__ float round_to(float v);
+template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_to<__bf16>(float v) { return (float)(__bf16)v; }
+
+// LayerNorm over the C = 16*NT channels of the lane's point; values in accumulator layout v[j][r] = channel 16j+4g+r
+template <int NT>
+__device__ __forceinline__ void row_norm(const f32x4* v, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  mean = groups_sum(s) * (1.0f / (16 * NT));
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float d = v[j][r] - mean; q += d * d; }
+  rstd = rsqrtf(groups_sum(q) * (1.0f / (16 * NT)) + eps);
+}
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  typedef typename Vec4<T>::type V4;
+  constexpr int C = 16 * NT, E = F::E, KC = F::KC;
+  constexpr int NKC = ChainFrag<T, NT>::NKC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + li;
+  if (((int64_t)blockIdx.x * 4 + wave) * 16 >= a.m) return;  // whole wave out of range
+  const bool valid = row < a.m;
+  const int64_t rc = valid ? row : a.m - 1;
+  const T* sc = reinterpret_cast<const T*>(a.shortcut);
+
+  f32x4 v[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = 16 * j + 4 * g;
+    if (a.slab) {
+      f32x4 acc = *reinterpret_cast<const f32x4*>(a.conv_bias + ch);
+      for (int z = 0; z < a.splits; ++z)
+        acc += *reinterpret_cast<const f32x4*>(a.slab + ((int64_t)z * a.m + rc) * C + ch);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[j][r] = round_to<T>(acc[r]);
+    } else {
+      float t[4];
+      unpack4<T>(*reinterpret_cast<const V4*>(reinterpret_cast<const T*>(a.x) + rc * C + ch), t);
+      v[j] = f32x4{t[0], t[1], t[2], t[3]};
+    }
+  }
+  float mean, rstd;
+  row_norm<NT>(v, a.eps, mean, rstd);
+  T* f1 = reinterpret_cast<T*>(a.f1);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = 16 * j + 4 * g;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g0 + ch), bt = *reinterpret_cast<const f32x4*>(a.b0 + ch);
+    float s[4];
+    unpack4<T>(*reinterpret_cast<const V4*>(sc + rc * C + ch), s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[j][r] = round_to<T>((v[j][r] - mean) * rstd * gm[r] + bt[r] + s[r]);
+    if (valid) *reinterpret_cast<V4*>(f1 + row * C + ch) = pack4<T>(v[j][0], v[j][1], v[j][2], v[j][3]);
+  }
+  row_norm<NT>(v, a.eps, mean, rstd);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = 16 * j + 4 * g;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g1 + ch), bt = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[j][r] = round_to<T>((v[j][r] - mean) * rstd * gm[r] + bt[r]);
+  }
+  FR xf[NKC];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) xf[kc] = ChainFrag<T, NT>::get(v, kc);
+
+  // qkv = t3 @ Wqkv^T + b : 3*NT output tiles, 4 at a time
+  const T* w = reinterpret_cast<const T*>(a.wqkv);
+  T* qkv = reinterpret_cast<T*>(a.qkv);
+  constexpr int OT = 3 * NT;
+  for (int o0 = 0; o0 < OT; o0 += 4) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) acc[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        if (o0 + jj < OT) {
+          FR wa = *reinterpret_cast<const FR*>(w + (int64_t)(16 * (o0 + jj) + li) * C + KC * kc + E * g);
+          acc[jj] = F::mma(wa, xf[kc], acc[jj]);
+        }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      if (o0 + jj < OT && valid) {
+        const int ch = 16 * (o0 + jj) + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bqkv + ch);
+        *reinterpret_cast<V4*>(qkv + row * (3 * C) + ch) =
+            pack4<T>(acc[jj][0] + b[0], acc[jj][1] + b[1], acc[jj][2] + b[2], acc[jj][3] + b[3]);
+      }
+  }
+}
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  typedef typename Vec4<T>::type V4;
+  constexpr int C = 16 * NT, E = F::E, KC = F::KC;
+  constexpr int NKC = ChainFrag<T, NT>::NKC;
+  constexpr int HKC = 64 / KC;  // K-chunks per 64-wide hidden slice (2 bf16 / 4 fp32)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + li;
+  if (((int64_t)blockIdx.x * 4 + wave) * 16 >= a.m) return;
+  const bool valid = row < a.m;
+  const int64_t rc = valid ? row : a.m - 1;
+  const T* attn = reinterpret_cast<const T*>(a.attn);
+  const T* f1 = reinterpret_cast<const T*>(a.f1);
+  const T* wp = reinterpret_cast<const T*>(a.wproj);
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+  const T* w2 = reinterpret_cast<const T*>(a.w2);
+
+  // ---- f2 = attn @ Wproj^T + b + f1   (attn rows are in natural channel order: natural Wproj)
+  f32x4 f2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) f2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kc = 0; kc < C / KC; ++kc) {
+    FR xb = *reinterpret_cast<const FR*>(attn + rc * C + KC * kc + E * g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      FR wa = *reinterpret_cast<const FR*>(wp + (int64_t)(16 * j + li) * C + KC * kc + E * g);
+      f2[j] = F::mma(wa, xb, f2[j]);
+    }
+  }
+  f32x4 t5[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = 16 * j + 4 * g;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bproj + ch);
+    float s[4];
+    unpack4<T>(*reinterpret_cast<const V4*>(f1 + rc * C + ch), s);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) f2[j][r] = round_to<T>(f2[j][r] + b[r] + s[r]);
+  }
+  float mean, rstd;
+  row_norm<NT>(f2, a.eps, mean, rstd);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = 16 * j + 4 * g;
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g2 + ch), bt = *reinterpret_cast<const f32x4*>(a.b2 + ch);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t5[j][r] = round_to<T>((f2[j][r] - mean) * rstd * gm[r] + bt[r]);
+  }
+  FR xf[NKC];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc) xf[kc] = ChainFrag<T, NT>::get(t5, kc);
+
+  // ---- out = f2 + fc2(GELU(fc1(t5))) : the hidden layer goes through registers 64 channels at a time
+  f32x4 o[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int h0 = 0; h0 < a.hidden; h0 += 64) {
+    f32x4 h[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) h[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        FR wa = *reinterpret_cast<const FR*>(w1 + (int64_t)(h0 + 16 * jj + li) * C + KC * kc + E * g);
+        h[jj] = F::mma(wa, xf[kc], h[jj]);
+      }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias1 + h0 + 16 * jj + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[jj][r] = round_to<T>(gelu_erf(h[jj][r] + b[r]));
+    }
+#pragma unroll
+    for (int m = 0; m < HKC; ++m) {
+      FR hf = ChainFrag<T, 4>::get(h, m);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        FR wa = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * m + E * g);
+        o[j] = F::mma(wa, hf, o[j]);
+      }
+    }
+  }
+  if (!valid) return;
+  T* out = reinterpret_cast<T*>(a.out);
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = 16 * j + 4 * g;
+    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias2 + ch);
+    *reinterpret_cast<V4*>(out + row * C + ch) =
+        pack4<T>(o[j][0] + b[0] + f2[j][0], o[j][1] + b[1] + f2[j][1], o[j][2] + b[2] + f2[j][2], o[j][3] + b[3] + f2[j][3]);
+  }
+}
+
+}  // namespace ptv3
+
+using namespace ptv3;
+
+#define FUSED_LAUNCH(KERNEL, ARGS)                                                                     \
+  {                                                                                                    \
+    dim3 grid((unsigned)cdiv(m, 64)), block(256);                                                      \
+    if (dtype == PTV3_F32) {                                                                           \
+      if (c == 32) hipLaunchKernelGGL((KERNEL<float, 2>), grid, block, 0, s, ARGS);                    \
+      else hipLaunchKernelGGL((KERNEL<float, 4>), grid, block, 0, s, ARGS);                            \
+    } else {                                                                                           \
+      if (c == 32) hipLaunchKernelGGL((KERNEL<__bf16, 2>), grid, block, 0, s, ARGS);                   \
+      else hipLaunchKernelGGL((KERNEL<__bf16, 4>), grid, block, 0, s, ARGS);                           \
+    }                                                                                                  \
+  }
+
+extern "C" int ptv3_block_fusable(int c, int hidden) {
+  return (c == 32 || c == 64) && hidden > 0 && hidden % 64 == 0;
+}
+
+extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias,
+                               const void* shortcut, const float* g0, const float* b0, const float* g1,
+                               const float* b1, const void* wqkv, const float* bqkv, void* f1, void* qkv, int64_t m,
+                               int c, float eps, int dtype, void* stream) {
+  PTV3_REQUIRE(ptv3_block_fusable(c, 64), "block_head: c=%d not in {32,64}", c);
+  PTV3_REQUIRE((x != nullptr) != (slab != nullptr), "block_head: give the conv output OR its split-K slabs");
+  PTV3_REQUIRE(slab == nullptr || (splits >= 1 && conv_bias != nullptr), "block_head: slabs need splits and the conv bias");
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "block_head: bad dtype");
+  if (m == 0) return PTV3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  HeadArgs a{x, slab, splits, conv_bias, shortcut, g0, b0, g1, b1, wqkv, bqkv, f1, qkv, m, eps};
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * 3 * c, ((double)m * c * 6 + 3.0 * c * c) * esz, nullptr, 0, 0.0);
+  FUSED_LAUNCH(block_head_kernel, a)
+  prof_end(prof, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wproj, const float* bproj,
+                               const float* g2, const float* b2, const void* w1, const float* bias1, const void* w2,
+                               const float* bias2, void* out, int64_t m, int c, int hidden, float eps, int dtype,
+                               void* stream) {
+  PTV3_REQUIRE(ptv3_block_fusable(c, hidden), "block_tail: c=%d / hidden=%d not fusable", c, hidden);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "block_tail: bad dtype");
+  if (m == 0) return PTV3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  TailArgs a{attn, f1, wproj, bproj, g2, b2, w1, bias1, w2, bias2, out, m, hidden, eps};
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * (c + 2.0 * hidden),
+                              ((double)m * c * 3 + (double)c * c + 2.0 * c * hidden) * esz, nullptr, 0, 0.0);
+  FUSED_LAUNCH(block_tail_kernel, a)
+  prof_end(prof, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}

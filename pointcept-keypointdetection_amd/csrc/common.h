@@ -82,6 +82,31 @@ __device__ __forceinline__ f32x4 mma16<__bf16>(s16x4 a, s16x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// 16-byte fragment of T: 4 fp32 or 8 bf16 consecutive K elements
+template <typename T> struct Frag;
+template <> struct Frag<float> {
+  typedef f32x4 type;
+  static constexpr int E = 4;    // elements per lane per fragment
+  static constexpr int KC = 16;  // K covered by one matrix-core chunk (4 lane groups x E)
+  static __device__ __forceinline__ f32x4 zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // 4 x v_mfma_f32_16x16x4_f32: exact fp32 fma chain
+  static __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) { return mma16<float>(a, b, c); }
+};
+template <> struct Frag<__bf16> {
+  typedef s16x8 type;
+  static constexpr int E = 8;
+  static constexpr int KC = 32;
+  static __device__ __forceinline__ s16x8 zero() { return s16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
+  // 1 x v_mfma_f32_16x16x32_bf16: lane (i, g) holds A[i][8g..8g+7], B[8g..8g+7][i]
+  static __device__ __forceinline__ f32x4 mma(s16x8 a, s16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                   0, 0, 0);
+  }
+};
+
 // erf by Abramowitz & Stegun 7.1.26 (|abs error| <= 1.5e-7, far inside the 1e-4 parity budget): one v_rcp and
 // one v_exp instead of libm's ~45-instruction erff -- the exact-GELU epilogue of fc1 was VALU-bound on erff.
 __device__ __forceinline__ float erf_fast(float x) {

@@ -202,18 +202,40 @@ struct Run {
     const int hidden = (int)(C * d->mlp_ratio);
     const size_t mark = F->off;
     const size_t row = (size_t)L.n * es;
-    void* t2 = F->alloc(row * C); void* f1 = F->alloc(row * C); void* t3 = F->alloc(row * C);
-    void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C); void* f2 = F->alloc(row * C);
-    void* t5 = F->alloc(row * C); void* t6 = F->alloc(row * hidden);
-    gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-    RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
-    gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
     const float scale = d->qk_scale > 0.f ? d->qk_scale : 1.0f / sqrtf((float)(C / H));
-    RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
-    gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
-    RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, sf));
-    gemm(t5, fc1_w, t6, L.n, C, hidden, 1, nullptr, nullptr, fc1_b, nullptr, nullptr, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
-    gemm(t6, fc2_w, L.feat, L.n, hidden, C, 1, nullptr, nullptr, fc2_b, nullptr, nullptr, 0, f2, nullptr, nullptr);
+    if (ptv3_block_fusable(C, hidden)) {
+      // conv -> [LN + shortcut + LN + qkv] -> window attention -> [proj + shortcut + LN + fc1 + GELU + fc2 + shortcut]
+      void* f1 = F->alloc(row * C); void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C);
+      const int splits = ptv3_gemm_splits(L.n, C, C, 27, d->dtype);
+      if (splits > 1) {
+        const size_t wsb = ptv3_gemm_workspace_bytes(L.n, C, C, 27, d->dtype);
+        float* slab = (float*)F->alloc(wsb);
+        RUN(ptv3_gemm(L.conv_feat, conv_w, nullptr, L.n, C, C, 27, L.nbr3, L.row_order, nullptr, nullptr, nullptr, 0,
+                      nullptr, nullptr, nullptr, d->dtype, slab, wsb, sf));
+        RUN(ptv3_block_head(nullptr, slab, splits, conv_b, L.feat, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b, f1, qkv, L.n,
+                            C, d->ln_eps, d->dtype, sf));
+      } else {
+        void* t2 = F->alloc(row * C);
+        gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+        RUN(ptv3_block_head(t2, nullptr, 0, nullptr, L.feat, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b, f1, qkv, L.n, C,
+                            d->ln_eps, d->dtype, sf));
+      }
+      RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
+      RUN(ptv3_block_tail(t4, f1, proj_w, proj_b, n2_g, n2_b, fc1_w, fc1_b, fc2_w, fc2_b, L.feat, L.n, C, hidden,
+                          d->ln_eps, d->dtype, sf));
+    } else {
+      void* t2 = F->alloc(row * C); void* f1 = F->alloc(row * C); void* t3 = F->alloc(row * C);
+      void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C); void* f2 = F->alloc(row * C);
+      void* t5 = F->alloc(row * C); void* t6 = F->alloc(row * hidden);
+      gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+      RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
+      gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+      RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
+      gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
+      RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, sf));
+      gemm(t5, fc1_w, t6, L.n, C, hidden, 1, nullptr, nullptr, fc1_b, nullptr, nullptr, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
+      gemm(t6, fc2_w, L.feat, L.n, hidden, C, 1, nullptr, nullptr, fc2_b, nullptr, nullptr, 0, f2, nullptr, nullptr);
+    }
     L.conv_feat = L.feat;
     F->off = mark;
   }

@@ -18,31 +18,6 @@ namespace ptv3 {
 constexpr int GM_THREADS = 256;
 constexpr int GM_BM = 64;  // points per workgroup (4 waves x 16)
 
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// 16-byte fragment of T: 4 fp32 or 8 bf16 consecutive K elements
-template <typename T> struct Frag;
-template <> struct Frag<float> {
-  typedef f32x4 type;
-  static constexpr int E = 4;    // elements per lane per fragment
-  static constexpr int KC = 16;  // K covered by one matrix-core chunk (4 lane groups x E)
-  static __device__ __forceinline__ f32x4 zero() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-  // 4 x v_mfma_f32_16x16x4_f32: exact fp32 fma chain
-  static __device__ __forceinline__ f32x4 mma(f32x4 a, f32x4 b, f32x4 c) { return mma16<float>(a, b, c); }
-};
-template <> struct Frag<__bf16> {
-  typedef s16x8 type;
-  static constexpr int E = 8;
-  static constexpr int KC = 32;
-  static __device__ __forceinline__ s16x8 zero() { return s16x8{0, 0, 0, 0, 0, 0, 0, 0}; }
-  // 1 x v_mfma_f32_16x16x32_bf16: lane (i, g) holds A[i][8g..8g+7], B[8g..8g+7][i]
-  static __device__ __forceinline__ f32x4 mma(s16x8 a, s16x8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
-                                                   0, 0, 0);
-  }
-};
-
 struct GemmArgs {
   const void* x; const void* w; void* out; void* out2; const void* res;
   const int32_t* nbr; const int32_t* row_order; const int32_t* res_index;
@@ -301,6 +276,11 @@ static int choose_splits(int64_t m, int cin, int cout, int kvol, int dtype, int*
 
 using namespace ptv3;
 
+extern "C" int ptv3_gemm_splits(int64_t m, int cin, int cout, int kvol, int dtype) {
+  int sps;
+  return choose_splits(m, cin, cout, kvol, dtype, &sps);
+}
+
 extern "C" size_t ptv3_gemm_workspace_bytes(int64_t m, int cin, int cout, int kvol, int dtype) {
   int sps;
   int splits = choose_splits(m, cin, cout, kvol, dtype, &sps);
@@ -326,6 +306,9 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
     splits = 1;  // caller gave no slab room: single pass
     sps = 0;
   }
+  // out == NULL: leave the raw fp32 slabs [splits][m][cout] in `workspace` (no bias / epilogue); a fused
+  // consumer (ptv3_block_head) sums them.  Only valid when the shape really splits (ptv3_gemm_splits > 1).
+  PTV3_REQUIRE(out != nullptr || splits > 1, "gemm: out == NULL needs a split-K shape and its workspace");
   int cin_shift = -1;
   if ((cin & (cin - 1)) == 0) { cin_shift = 0; while ((1 << cin_shift) < cin) ++cin_shift; }
   GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
@@ -350,7 +333,7 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   }
   if (dtype == PTV3_F32) { GM_LAUNCH(float) } else { GM_LAUNCH(__bf16) }
 #undef GM_LAUNCH
-  if (splits > 1) {
+  if (splits > 1 && out != nullptr) {
     GemmArgs r = a;
     r.row_order = nullptr;  // slabs are indexed by output row already
     const int64_t work = m * ((cout + 3) / 4);

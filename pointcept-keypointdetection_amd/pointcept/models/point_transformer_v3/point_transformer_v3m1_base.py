@@ -206,10 +206,53 @@ class Block(PointModule):
             return w.to(dtype).contiguous(), b.contiguous()
         return cache.get(("cpe", dtype), [conv.weight, conv.bias, lin.weight, lin.bias], make)
 
+    def chain_weights(self, dtype):
+        """(qkv, proj, fc1, fc2) weight matrices in `dtype`; the three GEMMs fed from registers by the fused block
+        kernels get their input channels permuted (ops.chain_permute), once per weight version."""
+        mlp = self.mlp[0]
+        cache = self.__dict__.setdefault("_fold_cache", _ParamCache())
+
+        def make():
+            cast = lambda w: w.detach().to(dtype).contiguous()  # noqa: E731
+            return (ops.chain_permute(cast(self.attn.qkv.weight), dtype), cast(self.attn.proj.weight),
+                    ops.chain_permute(cast(mlp.fc1.weight), dtype), ops.chain_permute(cast(mlp.fc2.weight), dtype))
+        return cache.get(("chain", dtype), [self.attn.qkv.weight, self.attn.proj.weight, mlp.fc1.weight,
+                                            mlp.fc2.weight], make)
+
+    def _forward_fused_kernels(self, point: Point):
+        """conv -> block_head -> window attention -> block_tail: 4 launches."""
+        mlp = self.mlp[0]
+        spt = point.sparse_conv_feat
+        dtype = spt.features.dtype
+        wf, bf = self.folded_cpe(dtype)
+        wqkv, wproj, w1, w2 = self.chain_weights(dtype)
+        nbr = spt.neighbors(3, self.cpe[0].indice_key)
+        g0, b0 = self.cpe[2].affine_f32()
+        g1, b1 = self.norm1[0].affine_f32()
+        g2, b2 = self.norm2[0].affine_f32()
+        eps = self.cpe[2].eps
+        slabs = ops.conv_slabs(spt.features, wf, nbr, 27, spt.row_order)
+        if slabs is not None:
+            f1, qkv = ops.block_head(None, slabs[0], slabs[1], bf, point.feat, g0, b0, g1, b1, wqkv,
+                                     self.attn.qkv.bias_f32(), eps)
+        else:
+            x = ops.gemm(spt.features, wf, bias=bf, nbr=nbr, kvol=27, row_order=spt.row_order)
+            f1, qkv = ops.block_head(x, None, 0, None, point.feat, g0, b0, g1, b1, wqkv, self.attn.qkv.bias_f32(), eps)
+        x = self.attn.attention_core(point, qkv)
+        feat = ops.block_tail(x, f1, wproj, self.attn.proj.bias_f32(), g2, b2, w1, mlp.fc1.bias_f32(), w2,
+                              mlp.fc2.bias_f32(), eps)
+        point.feat = feat
+        point.sparse_conv_feat = spt.replace_feature(feat)
+        return point
+
     def forward(self, point: Point):
         _no_training(self)
         if not self._fusable():
             return self._forward_generic(point)
+        mlp = self.mlp[0]
+        if (ops.block_fusable(self.channels, mlp.fc1.out_features) and isinstance(mlp.act, nn.GELU)
+                and self.cpe[2].eps == self.norm1[0].eps == self.norm2[0].eps):
+            return self._forward_fused_kernels(point)
         # ---- fused eval path: 9 launches per block, residual adds and norms folded into epilogues
         shortcut = point.feat
         spt = point.sparse_conv_feat                         # xCPE conv reads the sparse tensor's features

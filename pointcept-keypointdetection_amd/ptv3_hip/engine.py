@@ -74,13 +74,15 @@ class Packed:
     def _block(self, blk):
         cpe = blk.cpe
         wf, bf = blk.folded_cpe(self.dtype)   # conv with the cpe Linear folded in
-        out = [wf, bf,
-               _f32(cpe[2].weight), _f32(cpe[2].bias), _f32(blk.norm1[0].weight), _f32(blk.norm1[0].bias),
-               self._mat(blk.attn.qkv.weight), _f32(blk.attn.qkv.bias), self._mat(blk.attn.proj.weight),
-               _f32(blk.attn.proj.bias), _f32(blk.norm2[0].weight), _f32(blk.norm2[0].bias)]
         mlp = blk.mlp[0]
-        out += [self._mat(mlp.fc1.weight), _f32(mlp.fc1.bias), self._mat(mlp.fc2.weight), _f32(mlp.fc2.bias)]
-        return out
+        if ops.block_fusable(blk.channels, mlp.fc1.out_features):
+            wqkv, wproj, w1, w2 = blk.chain_weights(self.dtype)  # register-chained GEMMs: permuted inputs
+        else:
+            wqkv, wproj, w1, w2 = (self._mat(blk.attn.qkv.weight), self._mat(blk.attn.proj.weight),
+                                   self._mat(mlp.fc1.weight), self._mat(mlp.fc2.weight))
+        return [wf, bf, _f32(cpe[2].weight), _f32(cpe[2].bias), _f32(blk.norm1[0].weight), _f32(blk.norm1[0].bias),
+                wqkv, _f32(blk.attn.qkv.bias), wproj, _f32(blk.attn.proj.bias), _f32(blk.norm2[0].weight),
+                _f32(blk.norm2[0].bias), w1, _f32(mlp.fc1.bias), w2, _f32(mlp.fc2.bias)]
 
     def _pack(self):
         bb = self.backbone

@@ -32,6 +32,10 @@ SIGNATURES = {
     "ptv3_gemm_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "ptv3_gemm": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, c_int, P, c_size_t,
                           P]),
+    "ptv3_gemm_splits": (c_int, [c_int64, c_int, c_int, c_int, c_int]),
+    "ptv3_block_fusable": (c_int, [c_int, c_int]),
+    "ptv3_block_head": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
+    "ptv3_block_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_int, P]),
     "ptv3_layernorm": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     "ptv3_affine_act": (c_int, [P, P, P, c_int, P, c_int64, c_int, c_int, P]),
     "ptv3_cast": (c_int, [P, c_int, P, c_int, c_int64, P]),

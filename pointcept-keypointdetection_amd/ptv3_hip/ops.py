@@ -205,6 +205,59 @@ def gemm(x, w, bias=None, nbr=None, kvol=1, row_order=None, bn_scale=None, bn_sh
     return (out, out2) if dual else out
 
 
+def block_fusable(c, hidden):
+    return bool(lib.ptv3_block_fusable(int(c), int(hidden)))
+
+
+def chain_permute(w, dtype):
+    """Input-channel order the register-chained GEMMs of the fused block kernels expect (bf16: inside every
+    32-chunk [0-3,16-19,4-7,20-23,8-11,24-27,12-15,28-31]; fp32: unchanged)."""
+    if dtype == torch.float32:
+        return w
+    k = w.shape[1]
+    assert k % 32 == 0
+    base = [(4 * g + e) if e < 4 else (16 + 4 * g + e - 4) for g in range(4) for e in range(8)]
+    perm = torch.tensor([32 * q + b for q in range(k // 32) for b in base], device=w.device)
+    return w.index_select(1, perm).contiguous()
+
+
+def conv_slabs(x, w, nbr, kvol, row_order=None):
+    """Sparse conv left as split-K fp32 slabs (no bias): (slab tensor, splits) or None when the shape does not split."""
+    m, cin, cout = nbr.shape[0], x.shape[1], w.shape[0]
+    dt = _dt(x)
+    splits = lib.ptv3_gemm_splits(m, cin, cout, int(kvol), dt)
+    if splits <= 1:
+        return None
+    ws_bytes = lib.ptv3_gemm_workspace_bytes(m, cin, cout, int(kvol), dt)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    lib.check(lib.ptv3_gemm(_p(x), _p(w), None, m, cin, cout, int(kvol), _p(nbr), _p(row_order), None, None, None, 0,
+                            None, None, None, dt, _p(ws), ws_bytes, _stream()), "ptv3_gemm(slabs)")
+    return ws, splits
+
+
+def block_head(x, slab, splits, conv_bias, shortcut, g0, b0, g1, b1, wqkv, bqkv, eps):
+    """f1, qkv of the fused head (see ptv3_block_head)."""
+    _chk(shortcut, "shortcut", (torch.float32, torch.bfloat16), 2)
+    m, c = shortcut.shape
+    f1 = torch.empty_like(shortcut)
+    qkv = torch.empty((m, 3 * c), dtype=shortcut.dtype, device=shortcut.device)
+    lib.check(lib.ptv3_block_head(_p(x), _p(slab), int(splits), _p(conv_bias), _p(shortcut), _p(g0), _p(b0), _p(g1),
+                                  _p(b1), _p(wqkv), _p(bqkv), _p(f1), _p(qkv), m, c, float(eps), _dt(shortcut),
+                                  _stream()), "ptv3_block_head")
+    return f1, qkv
+
+
+def block_tail(attn, f1, wproj, bproj, g2, b2, w1, bias1, w2, bias2, eps):
+    _chk(attn, "attn", (torch.float32, torch.bfloat16), 2)
+    _chk(f1, "f1", attn.dtype, 2)
+    m, c = attn.shape
+    out = torch.empty_like(attn)
+    lib.check(lib.ptv3_block_tail(_p(attn), _p(f1), _p(wproj), _p(bproj), _p(g2), _p(b2), _p(w1), _p(bias1), _p(w2),
+                                  _p(bias2), _p(out), m, c, int(w1.shape[0]), float(eps), _dt(attn), _stream()),
+              "ptv3_block_tail")
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5, res=None, gamma2=None, beta2=None):
     """y = LN(x)*g+b (+res); with gamma2/beta2 also returns y2 = LN(y)*g2+b2."""
     _chk(x, "x", (torch.float32, torch.bfloat16), 2)

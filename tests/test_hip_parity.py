@@ -224,6 +224,42 @@ def test_subm_conv_vs_oracle(dev, n, cin, cout, k):
         assert (out.cpu() - ref).abs().max().item() < FP32_TOL
 
 
+@pytest.mark.parametrize("c,m", [(32, 1000), (64, 777), (64, 15), (32, 16)])
+def test_fused_block_halves_vs_torch(dev, c, m):
+    """ptv3_block_head / ptv3_block_tail (register-chained GEMMs) against plain torch fp32 of the same chain."""
+    from ptv3_hip import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(c)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    x, shortcut = rnd(m, c), rnd(m, c)
+    g0, b0, g1, b1, g2, b2 = (rnd(c) for _ in range(6))
+    wqkv, bqkv = rnd(3 * c, c) / c ** 0.5, rnd(3 * c)
+    wproj, bproj = rnd(c, c) / c ** 0.5, rnd(c)
+    w1, bias1 = rnd(4 * c, c) / c ** 0.5, rnd(4 * c)
+    w2, bias2 = rnd(c, 4 * c) / (4 * c) ** 0.5, rnd(c)
+    f1_ref = F.layer_norm(x, (c,), g0, b0, 1e-5) + shortcut
+    qkv_ref = F.linear(F.layer_norm(f1_ref, (c,), g1, b1, 1e-5), wqkv, bqkv)
+    attn = rnd(m, c)
+    f2 = F.linear(attn, wproj, bproj) + f1_ref
+    out_ref = f2 + F.linear(F.gelu(F.linear(F.layer_norm(f2, (c,), g2, b2, 1e-5), w1, bias1)), w2, bias2)
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, 0.15)):
+        cv = lambda t: d(t).to(dtype).contiguous()  # noqa: E731
+        perm = lambda w: ops.chain_permute(cv(w), dtype)  # noqa: E731
+        f1, qkv = ops.block_head(cv(x), None, 0, None, cv(shortcut), d(g0), d(b0), d(g1), d(b1), perm(wqkv), d(bqkv), 1e-5)
+        assert (f1.float().cpu() - f1_ref).abs().max().item() < tol
+        assert (qkv.float().cpu() - qkv_ref).abs().max().item() < tol
+        out = ops.block_tail(cv(attn), cv(f1_ref), cv(wproj), d(bproj), d(g2), d(b2), perm(w1), d(bias1), perm(w2),
+                             d(bias2), 1e-5)
+        assert (out.float().cpu() - out_ref).abs().max().item() < tol
+        # split-K slabs as the head's input: slabs sum + bias == x
+        if dtype == torch.float32:
+            slabs = torch.stack([x * 0.25, x * 0.5, x * 0.25 - 1.0]).contiguous()
+            f1s, _ = ops.block_head(None, d(slabs), 3, d(torch.ones(c)), cv(shortcut), d(g0), d(b0), d(g1), d(b1),
+                                    perm(wqkv), d(bqkv), 1e-5)
+            assert (f1s.cpu() - f1_ref).abs().max().item() < tol
+
+
 # ------------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------------
