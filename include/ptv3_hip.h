@@ -122,15 +122,20 @@ int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int cin, int c
               int dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- fused row-local halves of Block.forward (point_transformer_v3m1_base.py:318-338) ----------------
- * One wave carries 16 points through the whole chain in registers (no LDS, no barrier); available for
- * c in {32,64} and hidden % 64 == 0 (ptv3_block_fusable: the large-M levels), wider blocks use the entry
- * points above (small M: parallelism must come from the output-channel dimension).
- * bf16: wqkv, w1 (input dim c) and w2 (input dim hidden) must have their input channels permuted inside every
- * 32-chunk as [0-3,16-19,4-7,20-23,8-11,24-27,12-15,28-31] (see csrc/block_fused.hip); fp32: natural order.
+ * ptv3_block_fusable(c, hidden, dtype, m) names the variant the two entry points below will run:
+ *   1  c in {32,64} (the large-M levels): one wave carries 16 points through the whole chain in registers
+ *      (no LDS, no barrier). bf16: wqkv, w1 (input dim c) and w2 (input dim hidden) must have their input
+ *      channels permuted inside every 32-chunk as [0-3,16-19,4-7,20-23,8-11,24-27,12-15,28-31]
+ *      (see csrc/block_fused.hip); fp32: natural order.
+ *   2  c in {128,256,512}, hidden == 4c: one workgroup per 16 points, its waves split the output channels of
+ *      every GEMM, activations hop through LDS; natural weight layout. Every workgroup streams all 12c^2
+ *      weights, so the variant is only chosen up to a per-c row limit (default 16384 rows at c=128, off at
+ *      256/512; env PTV3_COOP_ROWS_<c>); m = 0 asks for the capability alone.
+ *   0  neither (use ptv3_gemm / ptv3_layernorm).
  *   head: x = conv output (or sum of its split-K slabs + conv_bias);
  *         f1 = LN(x; g0,b0) + shortcut;  qkv = LN(f1; g1,b1) @ wqkv^T + bqkv               (:319-324, :188)
  *   tail: f2 = attn @ wproj^T + bproj + f1;  out = f2 + fc2(GELU(fc1(LN(f2; g2,b2))))       (:219, :326-334) */
-int ptv3_block_fusable(int c, int hidden);
+int ptv3_block_fusable(int c, int hidden, int dtype, int64_t m);
 int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias, const void* shortcut,
                     const float* g0, const float* b0, const float* g1, const float* b1, const void* wqkv,
                     const float* bqkv, void* f1, void* qkv, int64_t m, int c, float eps, int dtype, void* stream);

@@ -17,6 +17,8 @@
 // output-channel dimension instead, i.e. from the tiled GEMM kernel (measured C=256, M=1388: 299 us fused vs
 // 40 us unfused), so wider blocks keep the unfused kernels.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
 
@@ -260,6 +262,242 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Workgroup-cooperative variants for the SMALL levels (C = 128 / 256 / 512, M <= a few thousand rows):
+// one workgroup owns 16 points; its NW = min(16, C/16) waves split the OUTPUT channels of every GEMM
+// of the chain (weights are read once per workgroup, each wave its share), activations hop between
+// the GEMMs through LDS in natural channel order (natural weight layout), 2-3 barriers per kernel.
+// With so few rows the chain is latency-bound: every wave issues 16 weight fragments before its
+// first MFMA and 4 waves per SIMD cover the rest.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct CoopPad { static constexpr int V = 16 / sizeof(T); };  // +16 bytes per LDS row
+template <int C> struct Coop {
+  static constexpr int NW = C / 16 < 16 ? C / 16 : 16;  // waves per workgroup
+  static constexpr int LPR = 4 * NW;                    // lanes per row in the LayerNorm stages
+  static constexpr int CPL = C / LPR;                   // channels per lane there (4 or 8)
+};
+
+// acc[t] (t < NTW) += W[tile q0 + NW*t][K] . act[16 rows][K]; act rows have stride `as` (LDS or global)
+template <typename T, int NTW, int NW>
+__device__ __forceinline__ void coop_tiles(f32x4 (&acc)[NTW], const T* __restrict__ w, int K, int ntiles, int q0,
+                                           const T* act, int as, int li, int g) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  constexpr int E = F::E, KC = F::KC;
+  constexpr int U = NTW >= 5 ? 2 : NTW >= 3 ? 4 : NTW == 2 ? 8 : 16;  // <= 16 fragments in flight
+  const T* wp[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    const int q = q0 + NW * t < ntiles ? q0 + NW * t : q0;  // inactive tiles alias an active one (results dropped)
+    wp[t] = w + (int64_t)(16 * q + li) * K + E * g;
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const T* ap = act + li * as + E * g;
+  const int nkc = K / KC;
+  for (int kc0 = 0; kc0 < nkc; kc0 += U) {
+    FR wa[NTW][U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+        wa[t][u] = *reinterpret_cast<const FR*>(wp[t] + KC * (kc0 + u < nkc ? kc0 + u : kc0));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (kc0 + u < nkc) {
+        const FR xf = *reinterpret_cast<const FR*>(ap + KC * (kc0 + u));
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) acc[t] = F::mma(wa[t][u], xf, acc[t]);
+      }
+    }
+  }
+}
+
+template <int CPL, int LPR>
+__device__ __forceinline__ void coop_row_stats(const float (&v)[CPL], int C, float eps, float& mean, float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) s += v[e];
+#pragma unroll
+  for (int d = 1; d < LPR; d <<= 1) s += __shfl_xor(s, d, 64);
+  mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int e = 0; e < CPL; ++e) { float dd = v[e] - mean; q += dd * dd; }
+#pragma unroll
+  for (int d = 1; d < LPR; d <<= 1) q += __shfl_xor(q, d, 64);
+  rstd = rsqrtf(q / (float)C + eps);
+}
+
+template <typename T, int C>
+__global__ void __launch_bounds__(64 * Coop<C>::NW) block_head_coop_kernel(HeadArgs a) {
+  typedef typename Vec4<T>::type V4;
+  constexpr int NW = Coop<C>::NW, LPR = Coop<C>::LPR, CPL = Coop<C>::CPL;
+  constexpr int TS = C + CoopPad<T>::V;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  T* sT = reinterpret_cast<T*>(smem);  // [16][TS]  LN1(f1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  // ---- stage 0: x (or slab sum + bias) -> LN0 + shortcut -> f1 ; LN1(f1) -> sT
+  {
+    const int rr = threadIdx.x / LPR, ll = threadIdx.x % LPR;  // row of the tile, lane inside the row
+    const int64_t row = r0 + rr;
+    const bool valid = row < a.m;
+    const int64_t rc = valid ? row : a.m - 1;
+    const int c0 = ll * CPL;
+    float v[CPL];
+#pragma unroll
+    for (int e4 = 0; e4 < CPL / 4; ++e4) {
+      const int ch = c0 + 4 * e4;
+      if (a.slab) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(a.conv_bias + ch);
+        for (int z = 0; z < a.splits; ++z)
+          acc += *reinterpret_cast<const f32x4*>(a.slab + ((int64_t)z * a.m + rc) * C + ch);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * e4 + r] = round_to<T>(acc[r]);
+      } else {
+        float t[4];
+        unpack4<T>(*reinterpret_cast<const V4*>(reinterpret_cast<const T*>(a.x) + rc * C + ch), t);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * e4 + r] = t[r];
+      }
+    }
+    float mean, rstd;
+    coop_row_stats<CPL, LPR>(v, C, a.eps, mean, rstd);
+    const T* sc = reinterpret_cast<const T*>(a.shortcut);
+    T* f1 = reinterpret_cast<T*>(a.f1);
+#pragma unroll
+    for (int e4 = 0; e4 < CPL / 4; ++e4) {
+      const int ch = c0 + 4 * e4;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g0 + ch), bt = *reinterpret_cast<const f32x4*>(a.b0 + ch);
+      float s4[4];
+      unpack4<T>(*reinterpret_cast<const V4*>(sc + rc * C + ch), s4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * e4 + r] = round_to<T>((v[4 * e4 + r] - mean) * rstd * gm[r] + bt[r] + s4[r]);
+      if (valid) *reinterpret_cast<V4*>(f1 + row * C + ch) = pack4<T>(v[4 * e4], v[4 * e4 + 1], v[4 * e4 + 2], v[4 * e4 + 3]);
+    }
+    coop_row_stats<CPL, LPR>(v, C, a.eps, mean, rstd);
+#pragma unroll
+    for (int e4 = 0; e4 < CPL / 4; ++e4) {
+      const int ch = c0 + 4 * e4;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g1 + ch), bt = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+      *reinterpret_cast<V4*>(sT + rr * TS + ch) =
+          pack4<T>((v[4 * e4] - mean) * rstd * gm[0] + bt[0], (v[4 * e4 + 1] - mean) * rstd * gm[1] + bt[1],
+                   (v[4 * e4 + 2] - mean) * rstd * gm[2] + bt[2], (v[4 * e4 + 3] - mean) * rstd * gm[3] + bt[3]);
+    }
+  }
+  __syncthreads();
+  // ---- stage 1: qkv, 3C/16 tiles dealt round-robin to the waves
+  constexpr int OT = 3 * C / 16, NTW = OT / NW;
+  static_assert(OT % NW == 0, "qkv tiles must divide over the waves");
+  f32x4 acc[NTW];
+  coop_tiles<T, NTW, NW>(acc, reinterpret_cast<const T*>(a.wqkv), C, OT, wave, sT, TS, li, g);
+  const int64_t row = r0 + li;
+  if (row < a.m) {
+    T* qkv = reinterpret_cast<T*>(a.qkv);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      const int ch = 16 * (wave + NW * t) + 4 * g;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bqkv + ch);
+      *reinterpret_cast<V4*>(qkv + row * (3 * C) + ch) =
+          pack4<T>(acc[t][0] + b[0], acc[t][1] + b[1], acc[t][2] + b[2], acc[t][3] + b[3]);
+    }
+  }
+}
+
+// HT = hidden / C (the mlp ratio, 1..4): tiles per wave of fc1 = HT * C / 16 / NW
+template <typename T, int C, int HT>
+__global__ void __launch_bounds__(64 * Coop<C>::NW) block_tail_coop_kernel(TailArgs a) {
+  typedef typename Vec4<T>::type V4;
+  constexpr int NW = Coop<C>::NW, LPR = Coop<C>::LPR, CPL = Coop<C>::CPL;
+  constexpr int HID = HT * C;
+  constexpr int FS = C + 4;                      // sF2 row stride (floats)
+  constexpr int TS = C + CoopPad<T>::V;          // sT row stride
+  constexpr int HS = HID + CoopPad<T>::V;        // sH row stride
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sF2 = reinterpret_cast<float*>(smem);   // [16][FS]  f2 (residual of the MLP)
+  T* sT = reinterpret_cast<T*>(sF2 + 16 * FS);   // [16][TS]  LN2(f2)
+  T* sH = sT + 16 * TS;                          // [16][HS]  GELU(fc1)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  const int64_t row = r0 + li;
+  const bool valid = row < a.m;
+  const int64_t rc = valid ? row : a.m - 1;
+  constexpr int NTC = C / 16, TWC = NTC / NW;    // channel tiles, per wave
+  // ---- stage A: f2 = attn @ Wproj^T + b + f1 (the activation rows come straight from global memory)
+  {
+    f32x4 acc[TWC];
+    coop_tiles<T, TWC, NW>(acc, reinterpret_cast<const T*>(a.wproj), C, NTC, wave,
+                           reinterpret_cast<const T*>(a.attn) + (rc - li) * C, C, li, g);
+    const T* f1 = reinterpret_cast<const T*>(a.f1);
+#pragma unroll
+    for (int t = 0; t < TWC; ++t) {
+      const int ch = 16 * (wave + NW * t) + 4 * g;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bproj + ch);
+      float s4[4];
+      unpack4<T>(*reinterpret_cast<const V4*>(f1 + rc * C + ch), s4);
+      *reinterpret_cast<f32x4*>(sF2 + li * FS + ch) =
+          f32x4{round_to<T>(acc[t][0] + b[0] + s4[0]), round_to<T>(acc[t][1] + b[1] + s4[1]),
+                round_to<T>(acc[t][2] + b[2] + s4[2]), round_to<T>(acc[t][3] + b[3] + s4[3])};
+    }
+  }
+  __syncthreads();
+  // ---- LN2
+  {
+    const int rr = threadIdx.x / LPR, ll = threadIdx.x % LPR;
+    const int c0 = ll * CPL;
+    float v[CPL];
+#pragma unroll
+    for (int e4 = 0; e4 < CPL / 4; ++e4) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(sF2 + rr * FS + c0 + 4 * e4);
+      v[4 * e4] = t[0]; v[4 * e4 + 1] = t[1]; v[4 * e4 + 2] = t[2]; v[4 * e4 + 3] = t[3];
+    }
+    float mean, rstd;
+    coop_row_stats<CPL, LPR>(v, C, a.eps, mean, rstd);
+#pragma unroll
+    for (int e4 = 0; e4 < CPL / 4; ++e4) {
+      const int ch = c0 + 4 * e4;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g2 + ch), bt = *reinterpret_cast<const f32x4*>(a.b2 + ch);
+      *reinterpret_cast<V4*>(sT + rr * TS + ch) =
+          pack4<T>((v[4 * e4] - mean) * rstd * gm[0] + bt[0], (v[4 * e4 + 1] - mean) * rstd * gm[1] + bt[1],
+                   (v[4 * e4 + 2] - mean) * rstd * gm[2] + bt[2], (v[4 * e4 + 3] - mean) * rstd * gm[3] + bt[3]);
+    }
+  }
+  __syncthreads();
+  // ---- stage B: h = GELU(t5 @ W1^T + b1) -> sH
+  {
+    constexpr int NTH = HID / 16, TWH = NTH / NW;
+    f32x4 acc[TWH];
+    coop_tiles<T, TWH, NW>(acc, reinterpret_cast<const T*>(a.w1), C, NTH, wave, sT, TS, li, g);
+#pragma unroll
+    for (int t = 0; t < TWH; ++t) {
+      const int ch = 16 * (wave + NW * t) + 4 * g;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias1 + ch);
+      *reinterpret_cast<V4*>(sH + li * HS + ch) =
+          pack4<T>(gelu_erf(acc[t][0] + b[0]), gelu_erf(acc[t][1] + b[1]), gelu_erf(acc[t][2] + b[2]),
+                   gelu_erf(acc[t][3] + b[3]));
+    }
+  }
+  __syncthreads();
+  // ---- stage C: out = h @ W2^T + b2 + f2
+  {
+    f32x4 acc[TWC];
+    coop_tiles<T, TWC, NW>(acc, reinterpret_cast<const T*>(a.w2), HID, NTC, wave, sH, HS, li, g);
+    if (valid) {
+      T* out = reinterpret_cast<T*>(a.out);
+#pragma unroll
+      for (int t = 0; t < TWC; ++t) {
+        const int ch = 16 * (wave + NW * t) + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias2 + ch);
+        const f32x4 r2 = *reinterpret_cast<const f32x4*>(sF2 + li * FS + ch);
+        *reinterpret_cast<V4*>(out + row * C + ch) =
+            pack4<T>(acc[t][0] + b[0] + r2[0], acc[t][1] + b[1] + r2[1], acc[t][2] + b[2] + r2[2], acc[t][3] + b[3] + r2[3]);
+      }
+    }
+  }
+}
+
 }  // namespace ptv3
 
 using namespace ptv3;
@@ -276,15 +514,72 @@ using namespace ptv3;
     }                                                                                                  \
   }
 
-extern "C" int ptv3_block_fusable(int c, int hidden) {
-  return (c == 32 || c == 64) && hidden > 0 && hidden % 64 == 0;
+// 0: not fusable, 1: wave-local register chain (C in {32,64}; bf16 wants chain-permuted weights),
+// 2: workgroup-cooperative (C in {128,256,512}; natural weights)
+static size_t coop_head_lds(int c, int esz) { return (size_t)16 * (c + 16 / esz) * esz; }
+static size_t coop_tail_lds(int c, int hidden, int esz) {
+  return (size_t)16 * (c + 4) * 4 + (size_t)16 * (c + 16 / esz) * esz + (size_t)16 * (hidden + 16 / esz) * esz;
 }
+
+// the cooperative variant re-reads the block's weights once per 16 points: past this many rows the
+// 64-row tiles of ptv3_gemm stream less
+static int64_t coop_max_rows(int c) {
+  static int64_t lim[3] = {-1, -1, -1};
+  const int i = c == 128 ? 0 : c == 256 ? 1 : 2;
+  if (lim[i] < 0) {
+    // measured on the 100k-point scene (tools/coop_sweep.sh): c=128 gains 3%, c=256 is neutral, c=512 loses --
+    // one CU cannot stream 9*c^2 weights fast enough, the separate GEMM launches spread them over the chip
+    const int64_t dflt[3] = {16384, 0, 0};
+    char name[32];
+    snprintf(name, sizeof name, "PTV3_COOP_ROWS_%d", c);
+    const char* e = getenv(name);
+    lim[i] = e ? atoll(e) : dflt[i];
+  }
+  return lim[i];
+}
+
+extern "C" int ptv3_block_fusable(int c, int hidden, int dtype, int64_t m) {
+  if (hidden <= 0 || hidden % 64 != 0 || (dtype != PTV3_F32 && dtype != PTV3_BF16)) return 0;
+  if (c == 32 || c == 64) return 1;
+  if ((c == 128 || c == 256 || c == 512) && hidden == 4 * c && m <= coop_max_rows(c) &&
+      coop_tail_lds(c, hidden, dtype == PTV3_F32 ? 4 : 2) <= 160 * 1024)
+    return 2;
+  return 0;
+}
+
+template <typename T, int C>
+static void launch_head_coop(const HeadArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((block_head_coop_kernel<T, C>), dim3((unsigned)cdiv(a.m, 16)), dim3(64 * Coop<C>::NW),
+                     coop_head_lds(C, sizeof(T)), s, a);
+}
+template <typename T, int C>
+static void launch_tail_coop(const TailArgs& a, hipStream_t s) {
+  static bool attr = false;  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_tail_coop_kernel<T, C, 4>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  hipLaunchKernelGGL((block_tail_coop_kernel<T, C, 4>), dim3((unsigned)cdiv(a.m, 16)), dim3(64 * Coop<C>::NW),
+                     coop_tail_lds(C, 4 * C, sizeof(T)), s, a);
+}
+#define COOP_LAUNCH(FN, ARGS)                                              \
+  if (dtype == PTV3_F32) {                                                 \
+    if (c == 128) FN<float, 128>(ARGS, s);                                 \
+    else if (c == 256) FN<float, 256>(ARGS, s);                            \
+    else FN<float, 512>(ARGS, s);                                          \
+  } else {                                                                 \
+    if (c == 128) FN<__bf16, 128>(ARGS, s);                                \
+    else if (c == 256) FN<__bf16, 256>(ARGS, s);                           \
+    else FN<__bf16, 512>(ARGS, s);                                         \
+  }
 
 extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias,
                                const void* shortcut, const float* g0, const float* b0, const float* g1,
                                const float* b1, const void* wqkv, const float* bqkv, void* f1, void* qkv, int64_t m,
                                int c, float eps, int dtype, void* stream) {
-  PTV3_REQUIRE(ptv3_block_fusable(c, 64), "block_head: c=%d not in {32,64}", c);
+  const int mode = ptv3_block_fusable(c, 4 * c, dtype, 0);  // m = 0: capability only, the row limits are the caller's policy
+  PTV3_REQUIRE(mode != 0, "block_head: c=%d not fusable", c);
   PTV3_REQUIRE((x != nullptr) != (slab != nullptr), "block_head: give the conv output OR its split-K slabs");
   PTV3_REQUIRE(slab == nullptr || (splits >= 1 && conv_bias != nullptr), "block_head: slabs need splits and the conv bias");
   PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "block_head: bad dtype");
@@ -293,7 +588,11 @@ extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, con
   HeadArgs a{x, slab, splits, conv_bias, shortcut, g0, b0, g1, b1, wqkv, bqkv, f1, qkv, m, eps};
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * 3 * c, ((double)m * c * 6 + 3.0 * c * c) * esz, nullptr, 0, 0.0);
-  FUSED_LAUNCH(block_head_kernel, a)
+  if (mode == 1) {
+    FUSED_LAUNCH(block_head_kernel, a)
+  } else {
+    COOP_LAUNCH(launch_head_coop, a)
+  }
   prof_end(prof, s);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
@@ -303,7 +602,8 @@ extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wpr
                                const float* g2, const float* b2, const void* w1, const float* bias1, const void* w2,
                                const float* bias2, void* out, int64_t m, int c, int hidden, float eps, int dtype,
                                void* stream) {
-  PTV3_REQUIRE(ptv3_block_fusable(c, hidden), "block_tail: c=%d / hidden=%d not fusable", c, hidden);
+  const int mode = ptv3_block_fusable(c, hidden, dtype, 0);
+  PTV3_REQUIRE(mode != 0, "block_tail: c=%d / hidden=%d not fusable", c, hidden);
   PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "block_tail: bad dtype");
   if (m == 0) return PTV3_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -311,7 +611,11 @@ extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wpr
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * (c + 2.0 * hidden),
                               ((double)m * c * 3 + (double)c * c + 2.0 * c * hidden) * esz, nullptr, 0, 0.0);
-  FUSED_LAUNCH(block_tail_kernel, a)
+  if (mode == 1) {
+    FUSED_LAUNCH(block_tail_kernel, a)
+  } else {
+    COOP_LAUNCH(launch_tail_coop, a)
+  }
   prof_end(prof, s);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;

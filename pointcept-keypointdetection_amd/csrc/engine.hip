@@ -203,7 +203,7 @@ struct Run {
     const size_t mark = F->off;
     const size_t row = (size_t)L.n * es;
     const float scale = d->qk_scale > 0.f ? d->qk_scale : 1.0f / sqrtf((float)(C / H));
-    if (ptv3_block_fusable(C, hidden)) {
+    if (ptv3_block_fusable(C, hidden, d->dtype, L.n)) {
       // conv -> [LN + shortcut + LN + qkv] -> window attention -> [proj + shortcut + LN + fc1 + GELU + fc2 + shortcut]
       void* f1 = F->alloc(row * C); void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C);
       const int splits = ptv3_gemm_splits(L.n, C, C, 27, d->dtype);

@@ -214,8 +214,10 @@ class Block(PointModule):
 
         def make():
             cast = lambda w: w.detach().to(dtype).contiguous()  # noqa: E731
-            return (ops.chain_permute(cast(self.attn.qkv.weight), dtype), cast(self.attn.proj.weight),
-                    ops.chain_permute(cast(mlp.fc1.weight), dtype), ops.chain_permute(cast(mlp.fc2.weight), dtype))
+            perm = ((lambda w: ops.chain_permute(w, dtype))
+                    if ops.block_fusable(self.channels, mlp.fc1.out_features, dtype) == 1 else (lambda w: w))
+            return (perm(cast(self.attn.qkv.weight)), cast(self.attn.proj.weight),
+                    perm(cast(mlp.fc1.weight)), perm(cast(mlp.fc2.weight)))
         return cache.get(("chain", dtype), [self.attn.qkv.weight, self.attn.proj.weight, mlp.fc1.weight,
                                             mlp.fc2.weight], make)
 
@@ -250,7 +252,7 @@ class Block(PointModule):
         if not self._fusable():
             return self._forward_generic(point)
         mlp = self.mlp[0]
-        if (ops.block_fusable(self.channels, mlp.fc1.out_features) and isinstance(mlp.act, nn.GELU)
+        if (ops.block_fusable(self.channels, mlp.fc1.out_features, point.feat.dtype, point.feat.shape[0]) and isinstance(mlp.act, nn.GELU)
                 and self.cpe[2].eps == self.norm1[0].eps == self.norm2[0].eps):
             return self._forward_fused_kernels(point)
         # ---- fused eval path: 9 launches per block, residual adds and norms folded into epilogues

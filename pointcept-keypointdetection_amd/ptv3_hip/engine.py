@@ -75,7 +75,7 @@ class Packed:
         cpe = blk.cpe
         wf, bf = blk.folded_cpe(self.dtype)   # conv with the cpe Linear folded in
         mlp = blk.mlp[0]
-        if ops.block_fusable(blk.channels, mlp.fc1.out_features):
+        if ops.block_fusable(blk.channels, mlp.fc1.out_features, self.dtype):
             wqkv, wproj, w1, w2 = blk.chain_weights(self.dtype)  # register-chained GEMMs: permuted inputs
         else:
             wqkv, wproj, w1, w2 = (self._mat(blk.attn.qkv.weight), self._mat(blk.attn.proj.weight),

@@ -33,7 +33,7 @@ SIGNATURES = {
     "ptv3_gemm": (c_int, [P, P, P, c_int64, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, c_int, P, c_size_t,
                           P]),
     "ptv3_gemm_splits": (c_int, [c_int64, c_int, c_int, c_int, c_int]),
-    "ptv3_block_fusable": (c_int, [c_int, c_int]),
+    "ptv3_block_fusable": (c_int, [c_int, c_int, c_int, c_int64]),
     "ptv3_block_head": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     "ptv3_block_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_int, P]),
     "ptv3_layernorm": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),

@@ -205,8 +205,10 @@ def gemm(x, w, bias=None, nbr=None, kvol=1, row_order=None, bn_scale=None, bn_sh
     return (out, out2) if dual else out
 
 
-def block_fusable(c, hidden):
-    return bool(lib.ptv3_block_fusable(int(c), int(hidden)))
+def block_fusable(c, hidden, dtype, m=0):
+    """0: no fused block kernels; 1: wave-local register chain (chain_permute'd weights); 2: workgroup-cooperative
+    (natural weights)."""
+    return int(lib.ptv3_block_fusable(int(c), int(hidden), _DT[dtype], int(m)))
 
 
 def chain_permute(w, dtype):

@@ -224,7 +224,8 @@ def test_subm_conv_vs_oracle(dev, n, cin, cout, k):
         assert (out.cpu() - ref).abs().max().item() < FP32_TOL
 
 
-@pytest.mark.parametrize("c,m", [(32, 1000), (64, 777), (64, 15), (32, 16)])
+@pytest.mark.parametrize("c,m", [(32, 1000), (64, 777), (64, 15), (32, 16), (128, 333), (256, 100), (256, 16),
+                                 (512, 37)])
 def test_fused_block_halves_vs_torch(dev, c, m):
     """ptv3_block_head / ptv3_block_tail (register-chained GEMMs) against plain torch fp32 of the same chain."""
     from ptv3_hip import ops
@@ -245,7 +246,11 @@ def test_fused_block_halves_vs_torch(dev, c, m):
     d = lambda t: t.to(dev).contiguous()  # noqa: E731
     for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, 0.15)):
         cv = lambda t: d(t).to(dtype).contiguous()  # noqa: E731
-        perm = lambda w: ops.chain_permute(cv(w), dtype)  # noqa: E731
+        mode = ops.block_fusable(c, 4 * c, dtype)          # m=0: which kernel variant exists for (c, dtype)
+        if mode == 0:                       # fp32 at c=512: the tail's LDS footprint exceeds a CU
+            assert (c, dtype) == (512, torch.float32)
+            continue
+        perm = (lambda w: ops.chain_permute(cv(w), dtype)) if mode == 1 else cv  # noqa: E731
         f1, qkv = ops.block_head(cv(x), None, 0, None, cv(shortcut), d(g0), d(b0), d(g1), d(b1), perm(wqkv), d(bqkv), 1e-5)
         assert (f1.float().cpu() - f1_ref).abs().max().item() < tol
         assert (qkv.float().cpu() - qkv_ref).abs().max().item() < tol
