@@ -236,6 +236,66 @@ size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int 
 int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
                  const ptv3_forward_io* io, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- training: backward kernels ---------------------------------------------------
+ * The reference has no hand-written backward on this path: torch autograd differentiates the forward
+ * statements cited at each forward entry point above.  These entry points are what a torch.autograd.Function
+ * per layer calls (pointcept-keypointdetection_amd/ptv3_hip/autograd.py).  All reductions over points use
+ * fixed row chunks -> fp32 slabs -> ordered sums (deterministic, no atomics).
+ *
+ * dw (cout, kvol*cin) fp32 = dy^T (m, cout) . gather(x (m, cin) through nbr (m, kvol))   [kvol=1: nbr NULL]
+ *   = weight gradient of nn.Linear (point_transformer_v3m1_base.py:188,219,232-244) and of SubMConv3d
+ *   (:277-284, 499-506) in the layout of ptv3_gemm's w.  Input gradients reuse ptv3_gemm itself: linear with
+ *   w^T; sparse conv with w'[c][t][o] = w[o][kvol-1-t][c] (submanifold neighbour maps are symmetric). */
+size_t ptv3_gemm_tn_workspace_bytes(int64_t m, int cout, int cin, int kvol);
+int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, int64_t m, int cout, int cin,
+                 int kvol, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* column reductions over the m rows of a (and b), out fp32:
+ *   mode 0: out[c]       = sum a                          (bias gradients)
+ *   mode 1: out[2][c]    = sum a, sum a*a                 (BatchNorm1d batch statistics, :439-441, 508-510)
+ *   mode 2: out[2][c]    = sum a, sum a*(b - mu)*rs       (BatchNorm1d backward: a = dy, b = x)
+ *   mode 3: out[2][c]    = sum a, sum (a - mu)^2          (centred second pass of the batch variance) */
+size_t ptv3_col_reduce_workspace_bytes(int64_t m, int c);
+int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, int mode, float* out,
+                    int64_t m, int c, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* LayerNorm backward (statistics recomputed from x): dx (m, c) dtype, dgamma_dbeta (2, c) fp32.
+ * workspace: ptv3_col_reduce_workspace_bytes(m, c). */
+int ptv3_layernorm_bwd(const void* x, const void* dy, const float* gamma, float eps, void* dx,
+                       float* dgamma_dbeta, int64_t m, int c, int dtype, void* workspace,
+                       size_t workspace_bytes, void* stream);
+/* dx = dy * act'(x * scale[c] + shift[c])  (scale = shift = NULL: act'(x)); act = PTV3_ACT_* */
+int ptv3_act_bwd(const void* dy, const void* x, const float* scale, const float* shift, int act, void* dx,
+                 int64_t m, int c, int dtype, void* stream);
+/* dx = ca[c]*dy + cb[c]*x + cc[c]: BatchNorm1d input gradient with the batch statistics folded into ca/cb/cc */
+int ptv3_affine2(const void* dy, const void* x, const float* ca, const float* cb, const float* cc, void* dx,
+                 int64_t m, int c, int dtype, void* stream);
+/* SerializedPooling segment-max backward (:416-421): the first member holding the maximum gets dy, others 0;
+ * SerializedUnpooling gather backward (:480): out[j] = sum of dy over the members of segment j. */
+int ptv3_pool_max_bwd(const void* feat, const void* dy, const int64_t* order0, const int32_t* seg_start,
+                      int64_t n_out, int c, void* dfeat, int dtype, void* stream);
+int ptv3_segment_sum(const void* dy, const int64_t* order0, const int32_t* seg_start, int64_t n_out, int c,
+                     void* out, int dtype, void* stream);
+/* window attention backward (:196-204 differentiated): qkv (n, 3c), out = forward output (n, c), dout (n, c)
+ * -> dqkv (n, 3c).  Softmax statistics are recomputed (nothing saved by the forward). rpe bias unsupported. */
+size_t ptv3_window_attn_bwd_workspace_bytes(int64_t n, int64_t n_pad, int c, int heads, int dtype);
+int ptv3_window_attn_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                         const int32_t* win_inverse, void* dqkv, int64_t n, int64_t n_pad, int c, int heads,
+                         int patch, float scale, int dtype, void* workspace, size_t workspace_bytes,
+                         void* stream);
+/* fused multi-tensor AdamW (torch.optim.AdamW semantics; pointcept/utils/optimizer.py builds it with one
+ * extra "block" parameter group): a device table of ptv3_adamw_entry_bytes()-sized entries, filled on the
+ * host by ptv3_adamw_fill_entry; entry i owns blocks [first_block_i, first_block_i + ceil(numel_i / chunk)).
+ * fp32 params / grads / moments.  grad_scale multiplies every gradient (1/loss-scale or a clip factor).
+ * ptv3_grad_sqnorm: out[0] = sum of squares of all gradients (clip_grad_norm_), partial_ws (total_blocks). */
+size_t ptv3_adamw_entry_bytes(void);
+int ptv3_adamw_chunk(void);
+int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
+                          int64_t numel, int group, int first_block);
+int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
+                    const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
+                    float grad_scale, void* stream);
+int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws, float* out,
+                     void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * While enabled, ptv3_gemm and ptv3_window_attn_fwd bracket their launches with HIP events on the launch
  * stream.  collect() synchronises the device and returns, per kernel family (0 linear, 1 subm_conv,

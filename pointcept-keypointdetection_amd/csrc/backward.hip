@@ -1,0 +1,482 @@
+// Backward kernels of the row-local layers of the PTv3 path (training):
+//   weight gradients of nn.Linear / SubMConv3d  (dW = dY^T . gather(X)), column reductions (bias, BatchNorm,
+//   LayerNorm affine gradients), LayerNorm / BatchNorm / activation input gradients, segment-max and
+//   gather backward of SerializedPooling / SerializedUnpooling.
+// All reductions over points are deterministic: fixed row chunks -> fp32 slabs -> slab-ordered sum.
+#include "common.h"
+#include "../../include/ptv3_hip.h"
+
+namespace ptv3 {
+
+// ------------------------------------------------------------------------------------------------
+// out[j] = sum_s slab[s][j]   (slab order = fixed summation order)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__ slab, int nslab, int64_t n,
+                                                       float* __restrict__ out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < nslab; ++z) s += slab[(int64_t)z * n + j];
+  out[j] = s;
+}
+
+static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, slab, nslab, n, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// dW[o][tap][c] = sum_i dY[i][o] * X[nbr[i][tap]][c]          (kvol = 1, nbr = NULL: plain dY^T X)
+// The contraction runs over POINTS, which are the slow axis of both operands, so the fp32 matrix core
+// (v_mfma_f32_16x16x4_f32: one k per lane group) is the natural fit: lane (i, g) feeds dY[r+g][o0+i] and
+// X[src(r+g)][c0+i] straight from global memory, 64 contiguous bytes per lane group, no transposition.
+// bf16 activations are widened on load; products and sums are exact fp32.
+// Workgroup = 64 x 64 output tile over one row chunk (4 waves, 32 x 32 each); chunks -> slabs.
+// ------------------------------------------------------------------------------------------------
+struct TnArgs {
+  const void* dy; const void* x; const int32_t* nbr; float* out;
+  int64_t m, rows_per_chunk, slab_stride;
+  int cout, cin, kvol, tiles_c;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int to = blockIdx.x / a.tiles_c, tc = blockIdx.x % a.tiles_c;
+  const int tap = blockIdx.y;
+  const int o0 = 64 * to + 32 * (wave >> 1), c0 = 64 * tc + 32 * (wave & 1);
+  const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_chunk;
+  const int64_t r1 = r0 + a.rows_per_chunk < a.m ? r0 + a.rows_per_chunk : a.m;
+  const bool ov[2] = {o0 + i < a.cout, o0 + 16 + i < a.cout};
+  const bool cv[2] = {c0 + i < a.cin, c0 + 16 + i < a.cin};
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; r += 4) {
+    const int64_t row = r + g;
+    const bool rv = row < r1;
+    int64_t src = row;
+    if (a.nbr) src = rv ? a.nbr[row * a.kvol + tap] : -1;
+    const bool sv = rv && src >= 0;
+    float av[2], bv[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      av[p] = (rv && ov[p]) ? to_f32<T>(dy[row * a.cout + o0 + 16 * p + i]) : 0.f;
+      bv[p] = (sv && cv[p]) ? to_f32<T>(x[src * a.cin + c0 + 16 * p + i]) : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[q], acc[p][q], 0, 0, 0);
+  }
+  // acc[p][q][r] = dW[o0 + 16p + 4g + r][tap][c0 + 16q + i]
+  float* out = a.out + (int64_t)blockIdx.z * a.slab_stride;
+  const int64_t ld = (int64_t)a.kvol * a.cin;
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 16 * p + 4 * g + r, c = c0 + 16 * q + i;
+        if (o < a.cout && c < a.cin) out[o * ld + (int64_t)tap * a.cin + c] = acc[p][q][r];
+      }
+}
+
+static int64_t tn_chunks(int64_t m, int64_t* rows_per_chunk) {
+  // at most 128 slabs; chunks are multiples of 4 rows (one matrix-core step)
+  int64_t rpc = cdiv(cdiv(m, 128), 4) * 4;
+  if (rpc < 1024) rpc = 1024;
+  *rows_per_chunk = rpc;
+  return cdiv(m, rpc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Column reductions over points.  Thread = (column of a 64-wide group, one of 4 row lanes);
+// block (bx, by) covers rows [bx*RB, (bx+1)*RB) x columns [64*by, 64*by+64) and writes one slab row.
+//   MODE 0: sum a                      MODE 1: sum a, sum a^2
+//   MODE 2: sum a, sum a * bhat  with bhat = (b - mu[c]) * rs[c]
+//   MODE 3: sum a, sum (a - mu[c])^2
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          const float* __restrict__ mu, const float* __restrict__ rs,
+                                                          int64_t m, int c, int64_t rb, float* __restrict__ slab) {
+  constexpr int NQ = MODE == 0 ? 1 : 2;
+  __shared__ float red[NQ][4][64];
+  const int t = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + t;
+  const int64_t r0 = (int64_t)blockIdx.x * rb, r1 = r0 + rb < m ? r0 + rb : m;
+  float s0 = 0.f, s1 = 0.f;
+  if (col < c) {
+    float mc = 0.f, rc = 1.f;
+    if (MODE == 2) { mc = mu[col]; rc = rs[col]; }
+    if (MODE == 3) mc = mu[col];
+    for (int64_t r = r0 + rl; r < r1; r += 4) {
+      const float va = to_f32<T>(a[r * c + col]);
+      s0 += va;
+      if (MODE == 1) s1 += va * va;
+      if (MODE == 2) s1 += va * ((to_f32<T>(b[r * c + col]) - mc) * rc);
+      if (MODE == 3) s1 += (va - mc) * (va - mc);
+    }
+  }
+  red[0][rl][t] = s0;
+  if (NQ == 2) red[NQ - 1][rl][t] = s1;
+  __syncthreads();
+  if (rl == 0 && col < c) {
+    // slab row layout: [q][c]
+    float* o = slab + (int64_t)blockIdx.x * NQ * c;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) o[q * c + col] = (red[q][0][t] + red[q][1][t]) + (red[q][2][t] + red[q][3][t]);
+  }
+}
+
+static int64_t col_chunks(int64_t m, int64_t* rb) {
+  int64_t r = cdiv(cdiv(m, 256), 4) * 4;
+  if (r < 256) r = 256;
+  *rb = r;
+  return cdiv(m, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward: one wave per row, lane owns columns lane, lane+64, ...  (c <= 64*NC)
+//   xhat = (x - mean) * rstd;  gdy = gamma * dy
+//   dx = rstd * (gdy - mean(gdy) - xhat * mean(gdy * xhat));  dgamma += dy * xhat;  dbeta += dy
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <typename T, int NC>
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                             const float* __restrict__ gamma, int64_t m, int c,
+                                                             float eps, int64_t rb, T* __restrict__ dx,
+                                                             float* __restrict__ slab) {
+  __shared__ float red[2][4][64 * NC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rb, r1 = r0 + rb < m ? r0 + rb : m;
+  float gm[NC], dg[NC], db[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int col = lane + 64 * k;
+    gm[k] = col < c ? gamma[col] : 0.f;
+    dg[k] = db[k] = 0.f;
+  }
+  const float inv_c = 1.0f / (float)c;
+  for (int64_t r = r0 + wave; r < r1; r += 4) {
+    float xv[NC], dv[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int col = lane + 64 * k;
+      xv[k] = col < c ? to_f32<T>(x[r * c + col]) : 0.f;
+      dv[k] = col < c ? to_f32<T>(dy[r * c + col]) : 0.f;
+      s += xv[k];
+    }
+    const float mean = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int col = lane + 64 * k;
+      const float d = col < c ? xv[k] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int col = lane + 64 * k;
+      xv[k] = col < c ? (xv[k] - mean) * rstd : 0.f;  // xhat
+      const float gdy = gm[k] * dv[k];
+      s1 += gdy;
+      s2 += gdy * xv[k];
+      dg[k] += dv[k] * xv[k];
+      db[k] += dv[k];
+    }
+    s1 = wave_sum(s1) * inv_c;
+    s2 = wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const int col = lane + 64 * k;
+      if (col < c) dx[r * c + col] = from_f32<T>(rstd * (gm[k] * dv[k] - s1 - xv[k] * s2));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    red[0][wave][lane + 64 * k] = dg[k];
+    red[1][wave][lane + 64 * k] = db[k];
+  }
+  __syncthreads();
+  // slab row: [dgamma (c) | dbeta (c)]
+  for (int j = threadIdx.x; j < 2 * c; j += 256) {
+    const int q = j / c, col = j % c;
+    slab[(int64_t)blockIdx.x * 2 * c + j] = (red[q][0][col] + red[q][1][col]) + (red[q][2][col] + red[q][3][col]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// elementwise backward pieces
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == PTV3_ACT_GELU) {
+    // d/dz [ z * Phi(z) ] = Phi(z) + z * phi(z)
+    const float cdf = 0.5f * (1.0f + erf_fast(z * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.5f * z * z * 1.44269504088896340736f);
+    return cdf + z * pdf;
+  }
+  if (act == PTV3_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// dx = dy * act'(x * scale[c] + shift[c])          (scale == NULL: act'(x))
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int act, T* __restrict__ dx, int64_t total4, int c) {
+  typedef typename Vec4<T>::type V4;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total4) return;
+  float d[4], v[4];
+  unpack4<T>(reinterpret_cast<const V4*>(dy)[j], d);
+  unpack4<T>(reinterpret_cast<const V4*>(x)[j], v);
+  const int col = (int)((j * 4) % c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float z = scale ? v[e] * scale[col + e] + shift[col + e] : v[e];
+    d[e] *= act_grad(z, act);
+  }
+  reinterpret_cast<V4*>(dx)[j] = pack4<T>(d[0], d[1], d[2], d[3]);
+}
+
+// dx = ca[c] * dy + cb[c] * x + cc[c]     (BatchNorm input gradient with the batch statistics folded in)
+template <typename T>
+__global__ void __launch_bounds__(256) affine2_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       const float* __restrict__ ca, const float* __restrict__ cb,
+                                                       const float* __restrict__ cc, T* __restrict__ dx,
+                                                       int64_t total4, int c) {
+  typedef typename Vec4<T>::type V4;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= total4) return;
+  float d[4], v[4];
+  unpack4<T>(reinterpret_cast<const V4*>(dy)[j], d);
+  unpack4<T>(reinterpret_cast<const V4*>(x)[j], v);
+  const int col = (int)((j * 4) % c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) d[e] = ca[col + e] * d[e] + cb[col + e] * v[e] + cc[col + e];
+  reinterpret_cast<V4*>(dx)[j] = pack4<T>(d[0], d[1], d[2], d[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// SerializedPooling max backward: the first member holding the maximum of (segment, channel) receives
+// the gradient, every other member 0 (each source row is a member of exactly one segment: dfeat is
+// fully written, no zero-fill needed).  SerializedUnpooling gather backward = segment sum.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool MAX>
+__global__ void __launch_bounds__(256) segment_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ dy,
+                                                           const int64_t* __restrict__ order0,
+                                                           const int32_t* __restrict__ seg_start, int64_t n_out, int c,
+                                                           T* __restrict__ out) {
+  // one thread per (segment, channel); consecutive threads = consecutive channels
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_out * c) return;
+  const int64_t j = t / c;
+  const int ch = (int)(t % c);
+  const int s0 = seg_start[j], s1 = seg_start[j + 1];
+  if (MAX) {
+    float mx = -INFINITY;
+    int arg = s0;
+    for (int p = s0; p < s1; ++p) {
+      const float v = to_f32<T>(feat[order0[p] * c + ch]);
+      if (v > mx) { mx = v; arg = p; }
+    }
+    const T g = dy[j * c + ch];
+    for (int p = s0; p < s1; ++p) out[order0[p] * c + ch] = p == arg ? g : from_f32<T>(0.f);
+  } else {
+    float s = 0.f;
+    for (int p = s0; p < s1; ++p) s += to_f32<T>(dy[order0[p] * c + ch]);
+    out[j * c + ch] = from_f32<T>(s);
+  }
+}
+
+}  // namespace ptv3
+
+using namespace ptv3;
+
+#define BWD_DTYPE_CHECK(name) PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, name ": bad dtype %d", dtype)
+
+extern "C" size_t ptv3_gemm_tn_workspace_bytes(int64_t m, int cout, int cin, int kvol) {
+  int64_t rpc;
+  const int64_t ns = tn_chunks(m, &rpc);
+  return ns > 1 ? (size_t)ns * cout * kvol * cin * sizeof(float) : 0;
+}
+
+extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, int64_t m, int cout,
+                            int cin, int kvol, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  BWD_DTYPE_CHECK("gemm_tn");
+  PTV3_REQUIRE(cout > 0 && cin > 0 && kvol >= 1 && m >= 0, "gemm_tn: bad shape m=%lld cout=%d cin=%d kvol=%d",
+               (long long)m, cout, cin, kvol);
+  PTV3_REQUIRE((kvol == 1) == (nbr == nullptr), "gemm_tn: nbr must be given exactly when kvol > 1");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nw = (int64_t)cout * kvol * cin;
+  if (m == 0) {
+    if (hipMemsetAsync(dw, 0, nw * sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
+    return PTV3_OK;
+  }
+  int64_t rpc;
+  const int64_t ns = tn_chunks(m, &rpc);
+  PTV3_REQUIRE(workspace_bytes >= ptv3_gemm_tn_workspace_bytes(m, cout, cin, kvol), "gemm_tn: workspace too small");
+  TnArgs a;
+  a.dy = dy; a.x = x; a.nbr = nbr;
+  a.out = ns > 1 ? (float*)workspace : dw;
+  a.m = m; a.rows_per_chunk = rpc; a.slab_stride = nw;
+  a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)cdiv(cin, 64);
+  dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)kvol, (unsigned)ns);
+  if (dtype == PTV3_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), 0, s, a);
+  if (ns > 1) slab_sum((const float*)workspace, (int)ns, nw, dw, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" size_t ptv3_col_reduce_workspace_bytes(int64_t m, int c) {
+  int64_t rb;
+  return (size_t)col_chunks(m, &rb) * 2 * c * sizeof(float);
+}
+
+extern "C" int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, int mode, float* out,
+                               int64_t m, int c, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  BWD_DTYPE_CHECK("col_reduce");
+  PTV3_REQUIRE(mode >= 0 && mode <= 3, "col_reduce: mode %d outside [0,3]", mode);
+  PTV3_REQUIRE(mode != 3 || mu, "col_reduce: mode 3 needs mu");
+  PTV3_REQUIRE(mode != 2 || (b && mu && rs), "col_reduce: mode 2 needs b, mu, rs");
+  PTV3_REQUIRE(c > 0 && m >= 0, "col_reduce: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int nq = mode == 0 ? 1 : 2;
+  if (m == 0) {
+    if (hipMemsetAsync(out, 0, (size_t)nq * c * sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
+    return PTV3_OK;
+  }
+  int64_t rb;
+  const int64_t ns = col_chunks(m, &rb);
+  PTV3_REQUIRE(workspace_bytes >= (size_t)ns * nq * c * sizeof(float), "col_reduce: workspace too small");
+  dim3 grid((unsigned)ns, (unsigned)cdiv(c, 64));
+#define CR_LAUNCH(T, MODE)                                                                                     \
+  hipLaunchKernelGGL((col_reduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)a, (const T*)b, mu, rs, m, c, \
+                     rb, (float*)workspace)
+  if (dtype == PTV3_F32) {
+    if (mode == 0) CR_LAUNCH(float, 0); else if (mode == 1) CR_LAUNCH(float, 1); else if (mode == 2) CR_LAUNCH(float, 2); else CR_LAUNCH(float, 3);
+  } else {
+    if (mode == 0) CR_LAUNCH(__bf16, 0); else if (mode == 1) CR_LAUNCH(__bf16, 1); else if (mode == 2) CR_LAUNCH(__bf16, 2); else CR_LAUNCH(__bf16, 3);
+  }
+#undef CR_LAUNCH
+  slab_sum((const float*)workspace, (int)ns, (int64_t)nq * c, out, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_layernorm_bwd(const void* x, const void* dy, const float* gamma, float eps, void* dx,
+                                  float* dgamma_dbeta, int64_t m, int c, int dtype, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  BWD_DTYPE_CHECK("layernorm_bwd");
+  PTV3_REQUIRE(c > 0 && c <= 1024, "layernorm_bwd: c=%d outside [1,1024]", c);
+  hipStream_t s = (hipStream_t)stream;
+  if (m == 0) {
+    if (hipMemsetAsync(dgamma_dbeta, 0, (size_t)2 * c * sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
+    return PTV3_OK;
+  }
+  int64_t rb;
+  const int64_t ns = col_chunks(m, &rb);
+  PTV3_REQUIRE(workspace_bytes >= (size_t)ns * 2 * c * sizeof(float), "layernorm_bwd: workspace too small");
+  const int nc = (int)cdiv(c, 64);
+#define LNB_LAUNCH(T, NC)                                                                                      \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, NC>), dim3((unsigned)ns), dim3(256), 0, s, (const T*)x, (const T*)dy, \
+                     gamma, m, c, eps, rb, (T*)dx, (float*)workspace)
+#define LNB_CASE(T)                                 \
+  if (nc <= 1) LNB_LAUNCH(T, 1);                    \
+  else if (nc <= 2) LNB_LAUNCH(T, 2);               \
+  else if (nc <= 4) LNB_LAUNCH(T, 4);               \
+  else if (nc <= 8) LNB_LAUNCH(T, 8);               \
+  else LNB_LAUNCH(T, 16);
+  if (dtype == PTV3_F32) { LNB_CASE(float) } else { LNB_CASE(__bf16) }
+#undef LNB_CASE
+#undef LNB_LAUNCH
+  slab_sum((const float*)workspace, (int)ns, (int64_t)2 * c, dgamma_dbeta, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_act_bwd(const void* dy, const void* x, const float* scale, const float* shift, int act, void* dx,
+                            int64_t m, int c, int dtype, void* stream) {
+  BWD_DTYPE_CHECK("act_bwd");
+  PTV3_REQUIRE(c > 0 && c % 4 == 0, "act_bwd: c=%d must be a multiple of 4", c);
+  PTV3_REQUIRE((scale == nullptr) == (shift == nullptr), "act_bwd: scale/shift must come together");
+  if (m == 0) return PTV3_OK;
+  const int64_t total4 = m * c / 4;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(total4, 256));
+  if (dtype == PTV3_F32)
+    hipLaunchKernelGGL(act_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, scale, shift,
+                       act, (float*)dx, total4, c);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dy, (const __bf16*)x, scale,
+                       shift, act, (__bf16*)dx, total4, c);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_affine2(const void* dy, const void* x, const float* ca, const float* cb, const float* cc,
+                            void* dx, int64_t m, int c, int dtype, void* stream) {
+  BWD_DTYPE_CHECK("affine2");
+  PTV3_REQUIRE(c > 0 && c % 4 == 0, "affine2: c=%d must be a multiple of 4", c);
+  if (m == 0) return PTV3_OK;
+  const int64_t total4 = m * c / 4;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(total4, 256));
+  if (dtype == PTV3_F32)
+    hipLaunchKernelGGL(affine2_kernel<float>, grid, dim3(256), 0, s, (const float*)dy, (const float*)x, ca, cb, cc,
+                       (float*)dx, total4, c);
+  else
+    hipLaunchKernelGGL(affine2_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)dy, (const __bf16*)x, ca, cb, cc,
+                       (__bf16*)dx, total4, c);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_pool_max_bwd(const void* feat, const void* dy, const int64_t* order0, const int32_t* seg_start,
+                                 int64_t n_out, int c, void* dfeat, int dtype, void* stream) {
+  BWD_DTYPE_CHECK("pool_max_bwd");
+  if (n_out == 0) return PTV3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(n_out * c, 256));
+  if (dtype == PTV3_F32)
+    hipLaunchKernelGGL((segment_bwd_kernel<float, true>), grid, dim3(256), 0, s, (const float*)feat, (const float*)dy,
+                       order0, seg_start, n_out, c, (float*)dfeat);
+  else
+    hipLaunchKernelGGL((segment_bwd_kernel<__bf16, true>), grid, dim3(256), 0, s, (const __bf16*)feat,
+                       (const __bf16*)dy, order0, seg_start, n_out, c, (__bf16*)dfeat);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_segment_sum(const void* dy, const int64_t* order0, const int32_t* seg_start, int64_t n_out, int c,
+                                void* out, int dtype, void* stream) {
+  BWD_DTYPE_CHECK("segment_sum");
+  if (n_out == 0) return PTV3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)cdiv(n_out * c, 256));
+  if (dtype == PTV3_F32)
+    hipLaunchKernelGGL((segment_bwd_kernel<float, false>), grid, dim3(256), 0, s, (const float*)nullptr,
+                       (const float*)dy, order0, seg_start, n_out, c, (float*)out);
+  else
+    hipLaunchKernelGGL((segment_bwd_kernel<__bf16, false>), grid, dim3(256), 0, s, (const __bf16*)nullptr,
+                       (const __bf16*)dy, order0, seg_start, n_out, c, (__bf16*)out);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}

@@ -1,0 +1,123 @@
+// Fused multi-tensor AdamW step (torch.optim.AdamW semantics, decoupled weight decay) for the training glue
+// (the reference builds torch.optim.AdamW through pointcept/utils/optimizer.py with one extra
+// parameter group for the "block" keyword).  One launch updates every parameter: a device table lists
+// (param, grad, exp_avg, exp_avg_sq, numel, group) per tensor, blocks find their tensor by binary search.
+#include "common.h"
+#include "../../include/ptv3_hip.h"
+
+namespace ptv3 {
+
+struct AdamWTensor {
+  float* p; const float* g; float* m; float* v;
+  int64_t numel; int32_t group; int32_t first_block;
+};
+
+struct AdamWGroups { float lr[8], wd[8]; };
+
+constexpr int ADAMW_CHUNK = 4096;  // elements per block
+
+__global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restrict__ tab, int ntensors,
+                                                     AdamWGroups grp, float beta1, float beta2, float eps,
+                                                     float bc1, float rsqrt_bc2, float grad_scale) {
+  // find the tensor owning this block
+  int lo = 0, hi = ntensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamWTensor t = tab[lo];
+  const int64_t base = (int64_t)(blockIdx.x - t.first_block) * ADAMW_CHUNK;
+  const float lr = grp.lr[t.group], wd = grp.wd[t.group];
+  const float step = lr / bc1;
+  for (int64_t j = base + threadIdx.x; j < base + ADAMW_CHUNK && j < t.numel; j += 256) {
+    const float g = t.g[j] * grad_scale;
+    float p = t.p[j] * (1.0f - lr * wd);
+    const float m = beta1 * t.m[j] + (1.0f - beta1) * g;
+    const float v = beta2 * t.v[j] + (1.0f - beta2) * g * g;
+    const float denom = sqrtf(v) * rsqrt_bc2 + eps;
+    p -= step * (m / denom);
+    t.p[j] = p; t.m[j] = m; t.v[j] = v;
+  }
+}
+
+// sum of squares of every gradient (for clip_grad_norm_): per-block partials -> one value, deterministic
+__global__ void __launch_bounds__(256) grad_sq_kernel(const AdamWTensor* __restrict__ tab, int ntensors,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[256];
+  int lo = 0, hi = ntensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamWTensor t = tab[lo];
+  const int64_t base = (int64_t)(blockIdx.x - t.first_block) * ADAMW_CHUNK;
+  float s = 0.f;
+  for (int64_t j = base + threadIdx.x; j < base + ADAMW_CHUNK && j < t.numel; j += 256) s += t.g[j] * t.g[j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ partial, int n, float* out) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) s += partial[j];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+}  // namespace ptv3
+
+using namespace ptv3;
+
+extern "C" size_t ptv3_adamw_entry_bytes(void) { return sizeof(AdamWTensor); }
+extern "C" int ptv3_adamw_chunk(void) { return ADAMW_CHUNK; }
+
+/* host helper: fill one table entry (the table is built on the host, then copied to the device by the caller) */
+extern "C" int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
+                                     int64_t numel, int group, int first_block) {
+  PTV3_REQUIRE(group >= 0 && group < 8, "adamw: group %d outside [0,8)", group);
+  AdamWTensor* e = (AdamWTensor*)entry_host;
+  e->p = (float*)param; e->g = (const float*)grad; e->m = (float*)exp_avg; e->v = (float*)exp_avg_sq;
+  e->numel = numel; e->group = group; e->first_block = first_block;
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
+                               const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
+                               float grad_scale, void* stream) {
+  PTV3_REQUIRE(ngroups >= 1 && ngroups <= 8, "adamw: ngroups %d outside [1,8]", ngroups);
+  PTV3_REQUIRE(step >= 1, "adamw: step must be >= 1");
+  if (ntensors == 0 || total_blocks == 0) return PTV3_OK;
+  AdamWGroups grp;
+  for (int i = 0; i < 8; ++i) { grp.lr[i] = i < ngroups ? lr_host[i] : 0.f; grp.wd[i] = i < ngroups ? wd_host[i] : 0.f; }
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const AdamWTensor*)table_dev, ntensors, grp, beta1, beta2, eps, (float)bc1,
+                     (float)(1.0 / sqrt(bc2)), grad_scale);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws,
+                                float* out, void* stream) {
+  if (ntensors == 0 || total_blocks == 0) {
+    if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return PTV3_ERR_LAUNCH;
+    return PTV3_OK;
+  }
+  hipLaunchKernelGGL(grad_sq_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const AdamWTensor*)table_dev, ntensors, partial_ws);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial_ws, total_blocks, out);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}

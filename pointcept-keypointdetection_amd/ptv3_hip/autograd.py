@@ -1,0 +1,260 @@
+"""torch.autograd.Function per layer of the PTv3 path: forward AND backward run in libptv3_hip.so.
+
+The reference trains through torch autograd over torch / spconv / torch_scatter ops
+(engines/train.py:184-213); here every differentiable layer of the path is one Function whose two halves call
+the C ABI (include/ptv3_hip.h, "training: backward kernels").  torch supplies the tape, device memory and the
+parameter tensors (fp32 masters; activations may be bf16: weights are cast per call, weight gradients are
+accumulated in fp32 by the kernels and returned in the parameter's dtype).
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+def _wmat(w, dtype, cin_pad=None):
+    """(cout, k..., cin) parameter -> (cout, kvol*cin_pad) K-contiguous matrix in `dtype`."""
+    w = w.detach()
+    if cin_pad is not None and cin_pad != w.shape[-1]:
+        w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[-1]))
+    return w.reshape(w.shape[0], -1).to(dtype).contiguous()
+
+
+def _pad_cols(x, gran):
+    pad = (-x.shape[1]) % gran
+    return torch.nn.functional.pad(x, (0, pad)).contiguous() if pad else x
+
+
+class LinearFn(Function):
+    """y = x W^T + b   (nn.Linear; point_transformer_v3m1_base.py:188, 219, 232-244)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        gran = ops.k_granule(x.dtype)
+        xp = _pad_cols(x.contiguous(), gran)
+        w = _wmat(weight, x.dtype, xp.shape[1])
+        ctx.save_for_backward(xp, weight)
+        ctx.has_bias = bias is not None
+        ctx.cin = x.shape[1]
+        return ops.gemm(xp, w, bias=None if bias is None else bias.detach().float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        gran = ops.k_granule(dy.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # dx = dy W : the same GEMM with the transposed weight (cin, cout); cout padded to the K granule
+            dyp = _pad_cols(dy, gran)
+            wt = weight.detach().to(dy.dtype).t()
+            wt = _pad_cols(wt.contiguous(), gran)
+            dx = ops.gemm(dyp, wt)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_tn(dy, xp)[:, :ctx.cin].to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_reduce(dy)
+        return dx, dw, db
+
+
+class SubMConvFn(Function):
+    """Submanifold sparse conv as implicit GEMM (spconv SubMConv3d; :277-284, 499-506).
+    weight (cout, k, k, k, cin); nbr (n, kvol) int32; row_order optional visiting order."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, nbr, row_order):
+        gran = ops.k_granule(x.dtype)
+        xp = _pad_cols(x.contiguous(), gran)
+        kvol = nbr.shape[1]
+        w = _wmat(weight, x.dtype, xp.shape[1])
+        ctx.save_for_backward(xp, weight, nbr, row_order)
+        ctx.has_bias = bias is not None
+        ctx.cin = x.shape[1]
+        return ops.gemm(xp, w, bias=None if bias is None else bias.detach().float().contiguous(), nbr=nbr,
+                        kvol=kvol, row_order=row_order)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight, nbr, row_order = ctx.saved_tensors
+        dy = dy.contiguous()
+        kvol = nbr.shape[1]
+        cout, cin = weight.shape[0], ctx.cin
+        gran = ops.k_granule(dy.dtype)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            # neighbour maps of a submanifold conv are symmetric: nbr[i][t] = j  <=>  nbr[j][kvol-1-t] = i, so
+            # dx[j] = sum_t dy[nbr[j][t]] . W[:, kvol-1-t, :]  -- the forward kernel on mirrored, transposed taps
+            dyp = _pad_cols(dy, gran)
+            w = weight.detach().reshape(cout, kvol, cin).flip(1).permute(2, 1, 0)  # (cin, kvol, cout)
+            if dyp.shape[1] != cout:
+                w = torch.nn.functional.pad(w, (0, dyp.shape[1] - cout))
+            wt = w.reshape(cin, -1).to(dy.dtype).contiguous()
+            dx = ops.gemm(dyp, wt, nbr=nbr, kvol=kvol, row_order=row_order)
+        if ctx.needs_input_grad[1]:
+            dw = ops.gemm_tn(dy, xp, nbr, kvol).view(cout, kvol, xp.shape[1])[:, :, :cin]
+            dw = dw.reshape(weight.shape).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_reduce(dy)
+        return dx, dw, db, None, None
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        g, b = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        ctx.pdtype = weight.dtype
+        return ops.layernorm(x, g, b, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(x, dy.contiguous(), g, ctx.eps)
+        return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
+
+
+class BatchNormActFn(Function):
+    """act(BatchNorm1d(x)) with batch statistics (training) or running statistics (eval)
+    (:439-442, 508-511; offset_keypoint_ptv3.py head).  Running buffers are updated in place like torch
+    (momentum, unbiased variance)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+        x = x.contiguous()
+        m = x.shape[0]
+        if training:
+            mean = ops.col_reduce(x) / m
+            var = ops.col_reduce(x, mu=mean.contiguous(), mode=3)[1] / m  # centred second pass (biased variance)
+            if running_mean is not None:
+                with torch.no_grad():
+                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                    unbiased = var * (m / max(m - 1, 1))
+                    running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        else:
+            mean, var = running_mean.float(), running_var.float()
+        rstd = torch.rsqrt(var + eps)
+        gamma = weight.detach().float()
+        scale = (gamma * rstd).contiguous()
+        shift = (bias.detach().float() - mean * scale).contiguous()
+        ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous(), gamma)
+        ctx.training, ctx.act, ctx.pdtype = training, act, weight.dtype
+        return ops.affine_act(x, scale, shift, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        m = x.shape[0]
+        dpre = ops.act_bwd(dy, x, ctx.act, scale, shift) if ctx.act != ops.ACT_NONE else dy
+        sums = ops.col_reduce(dpre, x, mean, rstd, mode=2)  # sum dpre, sum dpre * xhat
+        dbeta, dgamma = sums[0], sums[1]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.training:
+                k1, k2 = sums[0] / m, sums[1] / m
+                ca = gamma * rstd
+                cb = -ca * rstd * k2
+                cc = ca * (mean * rstd * k2 - k1)
+            else:
+                ca, cb, cc = scale, torch.zeros_like(scale), torch.zeros_like(scale)
+            dx = ops.affine2(dpre, x, ca.contiguous(), cb.contiguous(), cc.contiguous())
+        return dx, dgamma.to(ctx.pdtype), dbeta.to(ctx.pdtype), None, None, None, None, None, None
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.affine_act(x, None, None, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd(dy.contiguous(), x, ctx.act), None
+
+
+class WindowAttentionFn(Function):
+    """softmax(scale q k^T) v per serialized window, gather / scatter fused (:188-216)."""
+
+    @staticmethod
+    def forward(ctx, qkv, win_order, win_inverse, heads, patch, scale):
+        qkv = qkv.contiguous()
+        out = ops.window_attention(qkv, win_order, win_inverse, heads, patch, scale)
+        ctx.save_for_backward(qkv, out, win_order, win_inverse)
+        ctx.cfg = (heads, patch, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, win_order, win_inverse = ctx.saved_tensors
+        heads, patch, scale = ctx.cfg
+        return (ops.window_attention_bwd(qkv, out, dout.contiguous(), win_order, win_inverse, heads, patch, scale),
+                None, None, None, None, None)
+
+
+class SegmentMaxFn(Function):
+    """torch_scatter.segment_csr(feat[indices], idx_ptr, reduce="max") (:416-421) over serialized-order runs."""
+
+    @staticmethod
+    def forward(ctx, feat, order0, seg_start, n_out):
+        feat = feat.contiguous()
+        ctx.save_for_backward(feat, order0, seg_start)
+        return ops.pool_max(feat, order0, seg_start, n_out)
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, order0, seg_start = ctx.saved_tensors
+        return ops.pool_max_bwd(feat, dy.contiguous(), order0, seg_start), None, None, None
+
+
+class ClusterGatherFn(Function):
+    """point.feat[inverse] of SerializedUnpooling (:478): gather forward (index plumbing), deterministic
+    segment-sum backward."""
+
+    @staticmethod
+    def forward(ctx, feat, cluster, order0, seg_start):
+        ctx.save_for_backward(order0, seg_start)
+        ctx.n_out = feat.shape[0]
+        return feat.index_select(0, cluster)
+
+    @staticmethod
+    def backward(ctx, dy):
+        order0, seg_start = ctx.saved_tensors
+        return ops.segment_sum(dy.contiguous(), order0, seg_start, ctx.n_out), None, None, None
+
+
+def linear(x, weight, bias=None):
+    return LinearFn.apply(x, weight, bias)
+
+
+def subm_conv(x, weight, bias, nbr, row_order=None):
+    return SubMConvFn.apply(x, weight, bias, nbr, row_order)
+
+
+def layer_norm(x, weight, bias, eps):
+    return LayerNormFn.apply(x, weight, bias, eps)
+
+
+def batch_norm_act(x, bn, act=ops.ACT_NONE):
+    return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
+                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, act)
+
+
+def activation(x, act):
+    return ActFn.apply(x, act)
+
+
+def window_attention(qkv, win_order, win_inverse, heads, patch, scale):
+    return WindowAttentionFn.apply(qkv, win_order, win_inverse, heads, patch, scale)
+
+
+def segment_max(feat, order0, seg_start, n_out):
+    return SegmentMaxFn.apply(feat, order0, seg_start, n_out)
+
+
+def cluster_gather(feat, cluster, order0, seg_start):
+    return ClusterGatherFn.apply(feat, cluster, order0, seg_start)

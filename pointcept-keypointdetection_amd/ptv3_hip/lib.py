@@ -45,6 +45,23 @@ SIGNATURES = {
                                  P, P, P, c_int, P]),
     "ptv3_forward_workspace_bytes": (c_size_t, [P, c_int64, c_int]),
     "ptv3_forward": (c_int, [P, P, c_int, P, P, c_size_t, P]),
+    "ptv3_gemm_tn_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "ptv3_gemm_tn": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_size_t, P]),
+    "ptv3_col_reduce_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "ptv3_col_reduce": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "ptv3_layernorm_bwd": (c_int, [P, P, P, c_float, P, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "ptv3_act_bwd": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, c_int, P]),
+    "ptv3_affine2": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "ptv3_pool_max_bwd": (c_int, [P, P, P, P, c_int64, c_int, P, c_int, P]),
+    "ptv3_segment_sum": (c_int, [P, P, P, c_int64, c_int, P, c_int, P]),
+    "ptv3_window_attn_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    "ptv3_window_attn_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, P,
+                                     c_size_t, P]),
+    "ptv3_adamw_entry_bytes": (c_size_t, []),
+    "ptv3_adamw_chunk": (c_int, []),
+    "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
+    "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P]),
+    "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P]),
     "ptv3_profile_enable": (c_int, [c_int]),
     "ptv3_profile_collect": (c_int, [P, P, P, P]),
     "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),

@@ -350,6 +350,142 @@ def pool_reduce(feat, coord, grid_coord, batch, code, order0, seg_start, n_out, 
 
 
 # ---------------------------------------------------------------------------------------------
+# training: backward kernels
+# ---------------------------------------------------------------------------------------------
+_F = (torch.float32, torch.bfloat16)
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+
+
+def gemm_tn(dy, x, nbr=None, kvol=1):
+    """dW (cout, kvol*cin) fp32 = dy^T . gather(x): weight gradient of a Linear (kvol=1) or SubMConv3d."""
+    _chk(dy, "dy", _F, 2)
+    _chk(x, "x", dy.dtype, 2)
+    _chk(nbr, "nbr", torch.int32, 2)
+    m, cout = dy.shape
+    cin = x.shape[1]
+    if (nbr is None) != (kvol == 1) or (nbr is not None and tuple(nbr.shape) != (m, kvol)) or \
+            (nbr is None and x.shape[0] != m):
+        raise RuntimeError("gemm_tn: shape mismatch")
+    dw = torch.empty((cout, kvol * cin), dtype=torch.float32, device=dy.device)
+    nb = lib.ptv3_gemm_tn_workspace_bytes(m, cout, cin, int(kvol))
+    ws = _ws(nb, dy.device)
+    lib.check(lib.ptv3_gemm_tn(_p(dy), _p(x), _p(nbr), _p(dw), m, cout, cin, int(kvol), _dt(dy), _p(ws), nb,
+                               _stream()), "ptv3_gemm_tn")
+    return dw
+
+
+def col_reduce(a, b=None, mu=None, rs=None, mode=0):
+    """fp32 column sums over rows: mode 0 (c) sum a; 1 (2, c) sum a, sum a^2; 2 (2, c) sum a, sum a*(b-mu)*rs;
+    3 (2, c) sum a, sum (a-mu)^2."""
+    _chk(a, "a", _F, 2)
+    _chk(b, "b", a.dtype, 2)
+    _chk(mu, "mu", torch.float32, 1)
+    _chk(rs, "rs", torch.float32, 1)
+    m, c = a.shape
+    out = torch.empty((1 if mode == 0 else 2, c), dtype=torch.float32, device=a.device)
+    nb = lib.ptv3_col_reduce_workspace_bytes(m, c)
+    ws = _ws(nb, a.device)
+    lib.check(lib.ptv3_col_reduce(_p(a), _p(b), _p(mu), _p(rs), int(mode), _p(out), m, c, _dt(a), _p(ws), nb,
+                                  _stream()), "ptv3_col_reduce")
+    return out[0] if mode == 0 else out
+
+
+def layernorm_bwd(x, dy, gamma, eps):
+    """-> dx (m, c), dgamma (c), dbeta (c)."""
+    _chk(x, "x", _F, 2)
+    _chk(dy, "dy", x.dtype, 2)
+    _chk(gamma, "gamma", torch.float32, 1)
+    m, c = x.shape
+    dx = torch.empty_like(x)
+    dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
+    nb = lib.ptv3_col_reduce_workspace_bytes(m, c)
+    ws = _ws(nb, x.device)
+    lib.check(lib.ptv3_layernorm_bwd(_p(x), _p(dy), _p(gamma), float(eps), _p(dx), _p(dgb), m, c, _dt(x), _p(ws), nb,
+                                     _stream()), "ptv3_layernorm_bwd")
+    return dx, dgb[0], dgb[1]
+
+
+def act_bwd(dy, x, act, scale=None, shift=None):
+    """dy * act'(x*scale + shift)."""
+    _chk(dy, "dy", _F, 2)
+    _chk(x, "x", dy.dtype, 2)
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(shift, "shift", torch.float32, 1)
+    m, c = x.shape
+    dx = torch.empty_like(x)
+    lib.check(lib.ptv3_act_bwd(_p(dy), _p(x), _p(scale), _p(shift), int(act), _p(dx), m, c, _dt(x), _stream()),
+              "ptv3_act_bwd")
+    return dx
+
+
+def affine2(dy, x, ca, cb, cc):
+    """ca*dy + cb*x + cc per column."""
+    _chk(dy, "dy", _F, 2)
+    _chk(x, "x", dy.dtype, 2)
+    for t, nm in ((ca, "ca"), (cb, "cb"), (cc, "cc")):
+        _chk(t, nm, torch.float32, 1)
+    m, c = x.shape
+    dx = torch.empty_like(x)
+    lib.check(lib.ptv3_affine2(_p(dy), _p(x), _p(ca), _p(cb), _p(cc), _p(dx), m, c, _dt(x), _stream()), "ptv3_affine2")
+    return dx
+
+
+def pool_max(feat, order0, seg_start, n_out):
+    """segment max over the members of each cluster (the feature half of ptv3_pool_reduce, no BN / act)."""
+    _chk(feat, "feat", _F, 2)
+    _chk(order0, "order0", torch.int64, 1)
+    _chk(seg_start, "seg_start", torch.int32, 1)
+    n, c = feat.shape
+    out = torch.empty((n_out, c), dtype=feat.dtype, device=feat.device)
+    lib.check(lib.ptv3_pool_reduce(_p(feat), None, None, None, None, 1, _p(order0), _p(seg_start), n, n_out, c, 0, None,
+                                   None, ACT_NONE, None, _p(out), None, None, None, None, _dt(feat), _stream()),
+              "ptv3_pool_reduce")
+    return out
+
+
+def pool_max_bwd(feat, dy, order0, seg_start):
+    _chk(feat, "feat", _F, 2)
+    _chk(dy, "dy", feat.dtype, 2)
+    n_out, c = dy.shape
+    dfeat = torch.empty_like(feat)
+    lib.check(lib.ptv3_pool_max_bwd(_p(feat), _p(dy), _p(order0), _p(seg_start), n_out, c, _p(dfeat), _dt(feat),
+                                    _stream()), "ptv3_pool_max_bwd")
+    return dfeat
+
+
+def segment_sum(dy, order0, seg_start, n_out):
+    _chk(dy, "dy", _F, 2)
+    c = dy.shape[1]
+    out = torch.empty((n_out, c), dtype=dy.dtype, device=dy.device)
+    lib.check(lib.ptv3_segment_sum(_p(dy), _p(order0), _p(seg_start), n_out, c, _p(out), _dt(dy), _stream()),
+              "ptv3_segment_sum")
+    return out
+
+
+def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, scale):
+    _chk(qkv, "qkv", _F, 2)
+    _chk(out, "out", qkv.dtype, 2)
+    _chk(dout, "dout", qkv.dtype, 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    n_pad = win_order.shape[0]
+    if out.shape != (n, c) or dout.shape != (n, c) or win_inverse.shape[0] != n:
+        raise RuntimeError("window_attention_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    nb = lib.ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, int(heads), _dt(qkv))
+    ws = _ws(nb, qkv.device)
+    lib.check(lib.ptv3_window_attn_bwd(_p(qkv), _p(out), _p(dout), _p(win_order), _p(win_inverse), _p(dqkv), n, n_pad,
+                                       c, int(heads), int(patch), float(scale), _dt(qkv), _p(ws), nb, _stream()),
+              "ptv3_window_attn_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------------------------------------
 # pointops
 # ---------------------------------------------------------------------------------------------
 def knn_query(nsample, xyz, offset, new_xyz, new_offset):

@@ -1,0 +1,89 @@
+"""Fused multi-tensor AdamW on the HIP path (ptv3_adamw_step): one launch per optimizer step.
+
+Drop-in for torch.optim.AdamW as the reference builds it (pointcept/utils/optimizer.py: param groups with
+their own lr / weight_decay, e.g. the "block" keyword group of configs/my_dataset/offset_keypoint_ptv3.py);
+schedulers that rewrite group["lr"] between steps (OneCycleLR, engines/train.py:207-213) are honoured because
+lr / weight_decay travel as launch arguments, not in the device table.
+"""
+import ctypes
+
+import torch
+
+from .lib import lib
+from .ops import _stream
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) > 8:
+            raise ValueError("FusedAdamW: at most 8 parameter groups")
+        self._key = None
+        self._table = None
+        self._nt = self._nb = 0
+        self._partial = None
+        self._steps = 0
+
+    def _entries(self):
+        out = []
+        for gi, group in enumerate(self.param_groups):
+            if group["betas"] != self.param_groups[0]["betas"] or group["eps"] != self.param_groups[0]["eps"]:
+                raise ValueError("FusedAdamW: betas / eps must be shared by all groups")
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
+                    raise TypeError("FusedAdamW: fp32 GPU parameters and gradients only (masters stay fp32)")
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError("FusedAdamW: parameters and gradients must be contiguous")
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+                out.append((p, st, gi))
+        return out
+
+    def _build(self):
+        ent = self._entries()
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), gi) for p, _, gi in ent)
+        if key == self._key:
+            return
+        esz, chunk = lib.ptv3_adamw_entry_bytes(), lib.ptv3_adamw_chunk()
+        host = ctypes.create_string_buffer(max(1, esz * len(ent)))
+        base = ctypes.addressof(host)
+        blocks = 0
+        for i, (p, st, gi) in enumerate(ent):
+            lib.check(lib.ptv3_adamw_fill_entry(base + i * esz, p.data_ptr(), p.grad.data_ptr(),
+                                                st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi,
+                                                blocks), "ptv3_adamw_fill_entry")
+            blocks += (p.numel() + chunk - 1) // chunk
+        dev = ent[0][0].device if ent else torch.device("cuda")
+        self._table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
+        self._partial = torch.empty(max(blocks, 1), dtype=torch.float32, device=dev)
+        self._nt, self._nb, self._key = len(ent), blocks, key
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._build()
+        self._steps += 1
+        ng = len(self.param_groups)
+        lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
+        wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
+        b1, b2 = self.param_groups[0]["betas"]
+        lib.check(lib.ptv3_adamw_step(self._table.data_ptr(), self._nt, self._nb, lr, wd, ng, float(b1), float(b2),
+                                      float(self.param_groups[0]["eps"]), self._steps, float(grad_scale), _stream()),
+                  "ptv3_adamw_step")
+        return loss
+
+    @torch.no_grad()
+    def grad_norm(self):
+        """L2 norm of all gradients (0-d device tensor): the quantity clip_grad_norm_ computes."""
+        self._build()
+        out = torch.empty(1, dtype=torch.float32, device=self._table.device)
+        lib.check(lib.ptv3_grad_sqnorm(self._table.data_ptr(), self._nt, self._nb, self._partial.data_ptr(),
+                                       out.data_ptr(), _stream()), "ptv3_grad_sqnorm")
+        return out.sqrt_()[0]
