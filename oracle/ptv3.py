@@ -116,13 +116,33 @@ def window_attention_core(qkv, order, inverse, pad, unpad, H, K):
     return out[inv]
 
 
-class PTv3Oracle:
-    """Eval-mode functional forward of "PT-v3m1" (+ optional offset-keypoint / segmentor head)."""
+def _leafify(sd):
+    """training oracle: parameters become autograd leaves, buffers private copies."""
+    out = {}
+    for k, v in sd.items():
+        v = v.clone()
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            v.requires_grad_(True)
+        out[k] = v
+    return out
 
-    def __init__(self, cfg, state_dict, prefix=""):
+
+class PTv3Oracle:
+    """Functional forward of "PT-v3m1" (+ optional offset-keypoint / segmentor head).  Eval mode by default;
+    training=True: BatchNorm uses batch statistics and updates (private copies of) the running buffers
+    (momentum 0.01, v3m1_base.py:576), parameters are autograd leaves so that torch autograd over this
+    restatement yields the reference gradients (the reference trains through torch autograd,
+    engines/train.py:184-213).  DropPath is stochastic per point (RNG stream differs CPU vs device):
+    the training oracle requires drop_path = 0."""
+
+    def __init__(self, cfg, state_dict, prefix="", training=False):
         self.cfg = dict(cfg)
+        self.training = training
         self.sd = {k[len(prefix):]: v.detach().float().cpu() for k, v in state_dict.items()
                    if k.startswith(prefix)}
+        if training:
+            assert self.cfg.get("drop_path", 0.3) == 0.0, "training oracle: set drop_path=0 (stochastic depth RNG)"
+            self.sd = _leafify(self.sd)
         c = self.cfg
         self.order = [c["order"]] if isinstance(c["order"], str) else list(c["order"])
         self.enc_depths = c.get("enc_depths", (2, 2, 2, 6, 2))
@@ -144,7 +164,7 @@ class PTv3Oracle:
     def _bn(self, x, name, eps=1e-3):
         sd = self.sd
         return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
-                            sd[name + ".weight"], sd[name + ".bias"], False, 0.0, eps)
+                            sd[name + ".weight"], sd[name + ".bias"], self.training, 0.01, eps)
 
     def _ln(self, x, name):
         return F.layer_norm(x, (x.shape[1],), self.sd[name + ".weight"], self.sd[name + ".bias"], 1e-5)
@@ -285,19 +305,38 @@ class PTv3Oracle:
 
 
 class OffsetKeypointOracle:
-    """OffsetKeypointPTv3 (offset_keypoint_ptv3.py:6-107), eval mode."""
+    """OffsetKeypointPTv3 (offset_keypoint_ptv3.py:6-107); training=True as PTv3Oracle."""
 
-    def __init__(self, backbone_conf, state_dict, num_keypoints=6):
-        self.backbone = PTv3Oracle(backbone_conf, state_dict, prefix="backbone.")
+    def __init__(self, backbone_conf, state_dict, num_keypoints=6, training=False):
+        self.backbone = PTv3Oracle(backbone_conf, state_dict, prefix="backbone.", training=training)
+        self.training = training
         self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if k.startswith("head.")}
+        if training:
+            self.sd = _leafify(self.sd)
         self.K = num_keypoints
+
+    def named_parameters(self):
+        for k, v in self.backbone.sd.items():
+            if v.requires_grad:
+                yield "backbone." + k, v
+        for k, v in self.sd.items():
+            if v.requires_grad:
+                yield k, v
+
+    def named_buffers(self):
+        for k, v in self.backbone.sd.items():
+            if k.endswith(("running_mean", "running_var")):
+                yield "backbone." + k, v
+        for k, v in self.sd.items():
+            if k.endswith(("running_mean", "running_var")):
+                yield k, v
 
     def forward(self, data):
         P = self.backbone.backbone(data)
         sd = self.sd
         x = F.linear(P["feat"], sd["head.0.weight"], sd["head.0.bias"])
         x = F.batch_norm(x, sd["head.1.running_mean"], sd["head.1.running_var"],
-                         sd["head.1.weight"], sd["head.1.bias"], False, 0.0, 1e-5)
+                         sd["head.1.weight"], sd["head.1.bias"], self.training, 0.1, 1e-5)
         x = F.relu(x)
         x = F.linear(x, sd["head.3.weight"], sd["head.3.bias"])
         pred = x.view(-1, self.K, 4)

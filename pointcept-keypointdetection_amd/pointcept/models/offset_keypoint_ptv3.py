@@ -33,10 +33,13 @@ class OffsetKeypointPTv3(nn.Module):
         self.cls_criterion = nn.BCEWithLogitsLoss(reduction="none")
 
     def forward(self, data_dict):
-        _no_training(self)
-        point_output = self.backbone(data_dict, _head=self.head)
+        point_output = self.backbone(data_dict, _head=None if self.training else self.head)
         if "_head_out" in point_output.keys():   # head ran inside the native executor
             pred_flat = point_output.pop("_head_out")
+        elif self.training:
+            # Linear -> BatchNorm1d (batch statistics) + ReLU -> Linear, each a taped HIP Function
+            hidden = self.head[1](self.head[0](point_output.feat), act=ops.ACT_RELU)
+            pred_flat = self.head[3](hidden).float()
         else:
             feat = point_output.feat
             scale, shift = self.head[1].folded()

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from ptv3_hip import ops
+from ptv3_hip import autograd as A
 from ptv3_hip import engine as _engine
 from pointcept.models.builder import MODELS
 from pointcept.models.utils.misc import offset2bincount  # noqa: F401  (reference import surface)
@@ -124,14 +125,17 @@ class SerializedAttention(PointModule):
         wo, wi = self.window_maps(point)
         bias = None
         if self.enable_rpe:
+            _no_training(self)  # the backward kernel has no bias-gradient path yet
             bias = self.rpe(self.get_rel_pos(point, wo.long()))
+        if self.training:
+            return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale)
         return ops.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, rpe_bias=bias)
 
     def forward(self, point):
-        _no_training(self)
         qkv = self.qkv(point.feat)
         feat = self.attention_core(point, qkv)
         feat = self.proj(feat)
+        feat = self.proj_drop(feat)   # nn.Dropout: identity at the configs' proj_drop = 0 and in eval
         point.feat = feat
         return point
 
@@ -155,6 +159,10 @@ class MLP(nn.Module):
 
     def forward(self, x, res=None):
         act = self._act_id()
+        if self.training:
+            x = self.drop(self.act(self.fc1(x)))
+            x = self.drop(self.fc2(x))
+            return x if res is None else x + res
         if act is None:
             x = self.act(self.fc1(x))
         else:
@@ -248,8 +256,7 @@ class Block(PointModule):
         return point
 
     def forward(self, point: Point):
-        _no_training(self)
-        if not self._fusable():
+        if self.training or not self._fusable():
             return self._forward_generic(point)
         mlp = self.mlp[0]
         if (ops.block_fusable(self.channels, mlp.fc1.out_features, point.feat.dtype, point.feat.shape[0]) and isinstance(mlp.act, nn.GELU)
@@ -320,7 +327,6 @@ class SerializedPooling(PointModule):
         self.act = PointSequential(act_layer()) if act_layer is not None else None
 
     def forward(self, point: Point):
-        _no_training(self)
         pooling_depth = (math.ceil(self.stride) - 1).bit_length()
         if pooling_depth > point.serialized_depth:
             pooling_depth = 0
@@ -343,6 +349,7 @@ class SerializedPooling(PointModule):
         bn = self.norm[0] if self.norm is not None and len(self.norm) == 1 and isinstance(self.norm[0], BatchNorm1d) else None
         act_id = ops.ACT_NONE
         fuse = (self.norm is None or bn is not None) and (self.act is None or isinstance(self.act[0], nn.GELU))
+        fuse = fuse and not self.training   # training: BN needs the batch statistics of the pooled rows
         if fuse and self.act is not None:
             act_id = ops.ACT_GELU
         scale = shift = None
@@ -350,10 +357,12 @@ class SerializedPooling(PointModule):
             scale, shift = bn.folded()
         proj = self.proj(point.feat)
         feat, coord, grid_coord, batch, code_out = ops.pool_reduce(
-            proj, point.coord.float().contiguous() if "coord" in point.keys() else None,
+            proj.detach(), point.coord.float().contiguous() if "coord" in point.keys() else None,
             point.grid_coord.long().contiguous(), point.batch.long().contiguous(), code, order0, seg_start,
             n_out, pooling_depth, bn_scale=scale, bn_shift=shift, act=act_id if fuse else ops.ACT_NONE,
             row_perm=perm)
+        if self.training:
+            feat = A.segment_max(proj, order0, seg_start, n_out)   # taped twin of the max above
         depth = point.serialized_depth - pooling_depth
         end_bit = max(1, depth * 3 + max(nb - 1, 0).bit_length())
         order, inverse = ops.argsort_codes(code_out, end_bit)
@@ -373,6 +382,7 @@ class SerializedPooling(PointModule):
         if self.traceable:
             point_dict["pooling_inverse"] = cluster
             point_dict["pooling_parent"] = point
+            point_dict["_pool_segments"] = (order0, seg_start)   # for the deterministic gather backward
         point = point_dict
         if not fuse:
             if self.norm is not None:
@@ -417,12 +427,12 @@ class SerializedUnpooling(PointModule):
         return scale, shift, act
 
     def forward(self, point):
-        _no_training(self)
         assert "pooling_parent" in point.keys()
         assert "pooling_inverse" in point.keys()
         parent = point.pop("pooling_parent")
         inverse = point.pop("pooling_inverse")
-        e1, e2 = self._epilogue(self.proj), self._epilogue(self.proj_skip)
+        segments = point.pop("_pool_segments", None)
+        e1, e2 = (None, None) if self.training else (self._epilogue(self.proj), self._epilogue(self.proj_skip))
         if e1 is not None and e2 is not None:
             # two GEMMs: up-branch, then skip-branch whose epilogue gathers the up-branch rows by cluster id
             up = self.proj[0](point.feat, bn_scale=e1[0], bn_shift=e1[1], act=e1[2])
@@ -437,7 +447,10 @@ class SerializedUnpooling(PointModule):
         else:
             point = self.proj(point)
             parent = self.proj_skip(parent)
-            parent.feat = parent.feat + point.feat[inverse]
+            if self.training and segments is not None:
+                parent.feat = parent.feat + A.cluster_gather(point.feat, inverse, segments[0], segments[1])
+            else:
+                parent.feat = parent.feat + point.feat[inverse]
         if self.traceable:
             parent["unpooling_parent"] = point
         return parent
@@ -456,10 +469,9 @@ class Embedding(PointModule):
             self.stem.add(act_layer(), name="act")
 
     def forward(self, point: Point):
-        _no_training(self)
         mods = self.stem._modules
         bn, act = mods.get("norm"), mods.get("act")
-        if (bn is None or isinstance(bn, BatchNorm1d)) and (act is None or isinstance(act, nn.GELU)):
+        if not self.training and (bn is None or isinstance(bn, BatchNorm1d)) and (act is None or isinstance(act, nn.GELU)):
             scale, shift = bn.folded() if bn is not None else (None, None)
             sp = mods["conv"](point.sparse_conv_feat, bn_scale=scale, bn_shift=shift,
                               act=ops.ACT_GELU if act is not None else ops.ACT_NONE)
@@ -593,9 +605,9 @@ class PointTransformerV3(PointModule):
         return torch.float32
 
     def forward(self, data_dict, _head=None):
-        _no_training(self)
-        with torch.no_grad():
-            use_engine = self.use_engine and _engine.eligible(self, _head)
+        # eval: no autograd tape (fused kernels / native executor); train: one taped Function per layer
+        with torch.set_grad_enabled(self.training and torch.is_grad_enabled()):
+            use_engine = not self.training and self.use_engine and _engine.eligible(self, _head)
             if use_engine and "batch" not in data_dict and "offset" in data_dict and not isinstance(data_dict, Point):
                 # the executor derives the batch ids on its geometry stream: hand it an uninitialised buffer
                 data_dict = dict(data_dict)

@@ -3,12 +3,14 @@
 They subclass the torch classes the reference instantiates (nn.Linear, nn.LayerNorm, nn.BatchNorm1d,
 nn.GELU, nn.ReLU) so parameters, buffers, state_dict keys and isinstance checks are unchanged; only
 the arithmetic moves to the HIP kernels (ptv3_gemm / ptv3_layernorm / ptv3_affine_act).
-Inference only in this round: training-mode statistics / autograd are SURVEY section 8 row f1.
+`.eval()`: the fused inference kernels (no autograd tape).  `.train()`: one ptv3_hip.autograd Function per layer
+(forward and backward kernels of libptv3_hip.so, batch-statistic BatchNorm, DropPath) - SURVEY section 8 f1.
 """
 import torch
 import torch.nn as nn
 
 from ptv3_hip import ops
+from ptv3_hip import autograd as A
 from .sparse import _ParamCache
 
 
@@ -26,10 +28,23 @@ def bn_fold(bn, cache):
 
 
 def _no_training(m):
+    """Guard for the few layer variants that exist only as eval-mode kernels (e.g. RPE bias in attention)."""
     if m.training:
         raise NotImplementedError(
-            f"{type(m).__name__}: the HIP path implements the eval-mode forward only (call model.eval()); "
-            "training statistics and backward are SURVEY.md section 8 row f1")
+            f"{type(m).__name__}: this configuration has an eval-mode forward only on the HIP path")
+
+
+def _train_epilogue(y, epilogue):
+    """The GEMM epilogues the eval kernels fuse, as separate taped ops in training."""
+    extra = set(epilogue) - {"act", "res"}
+    if extra:
+        raise NotImplementedError(f"training-mode Linear: epilogue {sorted(extra)} is an eval-only fusion")
+    act = epilogue.get("act", ops.ACT_NONE)
+    if act != ops.ACT_NONE:
+        y = A.activation(y, act)
+    if epilogue.get("res") is not None:
+        y = y + epilogue["res"]
+    return y
 
 
 class Linear(nn.Linear):
@@ -46,6 +61,8 @@ class Linear(nn.Linear):
         return self._cache.get("b", [self.bias], lambda: _f32(self.bias))
 
     def forward(self, x, **epilogue):
+        if self.training:
+            return _train_epilogue(A.linear(x, self.weight, self.bias), epilogue)
         pad = (-x.shape[1]) % ops.k_granule(x.dtype)
         w = self.weight_for(x.dtype)
         if pad:  # 16-byte K granularity of the kernel
@@ -63,6 +80,9 @@ class LayerNorm(nn.LayerNorm):
         return self._cache.get("gb", [self.weight, self.bias], lambda: (_f32(self.weight), _f32(self.bias)))
 
     def forward(self, x, res=None):
+        if self.training:
+            y = A.layer_norm(x, self.weight, self.bias, self.eps)
+            return y if res is None else y + res
         g, b = self.affine_f32()
         return ops.layernorm(x, g, b, self.eps, res=res)
 
@@ -76,23 +96,32 @@ class BatchNorm1d(nn.BatchNorm1d):
         return bn_fold(self, self._cache)
 
     def forward(self, x, act=ops.ACT_NONE):
-        _no_training(self)
+        if self.training:
+            if self.track_running_stats and self.num_batches_tracked is not None:
+                self.num_batches_tracked.add_(1)
+            return A.batch_norm_act(x, self, act)
         s, t = self.folded()
         return ops.affine_act(x, s, t, act)
 
 
 class GELU(nn.GELU):
     def forward(self, x):
+        if self.training:
+            return A.activation(x, ops.ACT_GELU)
         return ops.affine_act(x, None, None, ops.ACT_GELU)
 
 
 class ReLU(nn.ReLU):
     def forward(self, x):
+        if self.training:
+            return A.activation(x, ops.ACT_RELU)
         return ops.affine_act(x, None, None, ops.ACT_RELU)
 
 
 class DropPath(nn.Module):
-    """timm.layers.DropPath: identity in eval mode (the only mode of this round)."""
+    """timm.layers.DropPath (timm 1.0.22 drop_path): identity in eval mode; in training one Bernoulli draw per
+    ROW of the (N, C) feature matrix - PointSequential hands DropPath the point features, so the reference drops
+    per point, not per scene (point_transformer_v3m1_base.py:314-316) - scaled by 1/keep_prob."""
 
     def __init__(self, drop_prob=0.0, scale_by_keep=True):
         super().__init__()
@@ -101,7 +130,11 @@ class DropPath(nn.Module):
     def forward(self, x):
         if self.drop_prob == 0.0 or not self.training:
             return x
-        _no_training(self)
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)  # RNG + mask: torch plumbing
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
 
     def extra_repr(self):
         return f"drop_prob={round(self.drop_prob, 3):0.3f}"

@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from ptv3_hip import ops
+from ptv3_hip import autograd as A
 
 
 class SparseConvTensor:
@@ -92,6 +93,11 @@ class SubMConv3d(nn.Module):
         return self._cache.get(("w", dtype, cin_pad), [self.weight], make)
 
     def forward(self, x: SparseConvTensor, bn_scale=None, bn_shift=None, act=ops.ACT_NONE):
+        if self.training:
+            if bn_scale is not None or act != ops.ACT_NONE:
+                raise NotImplementedError("training-mode SubMConv3d: BN / activation epilogues are eval-only fusions")
+            nbr = x.neighbors(self.kernel_size, self.indice_key)
+            return x.replace_feature(A.subm_conv(x.features, self.weight, self.bias, nbr, x.row_order))
         feat = x.features
         cin = feat.shape[1]
         gran = ops.k_granule(feat.dtype)

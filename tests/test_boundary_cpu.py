@@ -48,6 +48,11 @@ def test_no_cpu_fallback():
         ops.sfc_encode(torch.zeros(4, 3, dtype=torch.int64), torch.zeros(4, dtype=torch.int64), 3, ["z"])
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ops.gemm(torch.zeros(4, 4), torch.zeros(4, 4))
+    from ptv3_hip import autograd as A
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        A.linear(torch.zeros(4, 8, requires_grad=True), torch.zeros(8, 8), None)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.gemm_tn(torch.zeros(4, 8), torch.zeros(4, 8))
 
 
 def test_registry_semantics():
@@ -89,8 +94,12 @@ def test_models_registered_and_state_dict_matches_reference(golden_dir):
     ref = open(os.path.join(golden_dir, "state_dict_fork_cfg.txt")).read().strip().split("\n")
     assert mine == ref
     assert sum(p.numel() for p in model.backbone.parameters()) == 46158272
-    with pytest.raises(NotImplementedError):
-        model.train()(dict())
+    # training and eval both run on the HIP path only: CPU tensors are refused, never silently computed
+    import ptv3_scenes as S
+    data = S.make_batch([300], in_channels=4, extent=32, seed=0, with_target=6)
+    for mode in (True, False):
+        with pytest.raises(RuntimeError, match="GPU tensor|No HIP GPUs"):
+            model.train(mode)(data)
     seg = build_model(dict(type="DefaultSegmentorV2", num_classes=19, backbone_out_channels=64,
                            backbone=dict(type="PT-v3m1", **FORK_CFG)))
     assert tuple(seg.seg_head.weight.shape) == (19, 64)

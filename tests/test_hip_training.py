@@ -1,0 +1,146 @@
+"""GPU parity of a whole training step: OffsetKeypointPTv3.train() forward + backward on the HIP
+path against torch autograd over the oracle (CPU fp32 restatement, training=True): loss, every parameter
+gradient, BatchNorm running statistics, and the fused AdamW update.  drop_path = 0 in these configs (the
+DropPath Bernoulli stream cannot be shared between CPU and device); DropPath itself is tested on its own."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from make_golden_cfg import TINY_CFG, FORK_CFG  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch.device("cuda:0")
+
+
+def _build(cfg, hidden_dim=256):
+    from pointcept.models import build_model
+    return build_model(dict(type="OffsetKeypointPTv3", num_keypoints=6, hidden_dim=hidden_dim,
+                            backbone_conf=dict(type="PT-v3m1", **cfg)))
+
+
+def _perturb_stats(model, seed=99):
+    gen = torch.Generator().manual_seed(seed)
+    for n, b in model.named_buffers():
+        if n.endswith("running_mean"):
+            b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
+        if n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+
+
+def _rel(got, ref, floor=1e-6):
+    return (got.detach().float().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), floor)
+
+
+@pytest.mark.parametrize("cfg_name,sizes,hidden", [("tiny", [900, 700], 32), ("fork", [5000, 3000], 256)])
+def test_train_step_vs_oracle_autograd(dev, cfg_name, sizes, hidden):
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    cfg = dict(TINY_CFG if cfg_name == "tiny" else FORK_CFG, drop_path=0.0)
+    torch.manual_seed(1234)
+    model = _build(cfg, hidden_dim=hidden)
+    _perturb_stats(model)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    data = S.make_batch(sizes, in_channels=4, extent=96, seed=21, with_target=6)
+    # ---- reference: torch autograd over the oracle
+    orc = O.OffsetKeypointOracle(cfg, sd, training=True)
+    torch.manual_seed(5)
+    ref = orc.forward(data)
+    ref["loss"].backward()
+    ref_grads = {k: v.grad for k, v in orc.named_parameters()}
+    ref_bufs = dict(orc.named_buffers())
+    # ---- HIP path
+    model = model.to(dev).train()
+    torch.manual_seed(5)
+    out = model({k: v.to(dev) for k, v in data.items()})
+    assert set(out) >= {"loss", "train/cls_loss", "train/reg_loss", "train/offset_l1_err"}
+    assert all(torch.is_tensor(v) and v.dim() == 0 for v in out.values())   # 0-d tensors
+    out["loss"].backward()
+    assert abs(out["loss"].item() - ref["loss"].item()) < 1e-4
+    missing = [n for n, p in model.named_parameters() if p.grad is None]
+    assert not missing, f"parameters without gradient (DDP find_unused_parameters=False needs all): {missing[:5]}"
+    # per-parameter max error relative to that gradient's scale; gradients that are analytically zero (a bias
+    # feeding a batch-statistic BatchNorm) are measured against 1e-3 of the largest gradient instead
+    gmax = max(g.abs().max().item() for g in ref_grads.values())
+    worst = max(((n, _rel(p.grad, ref_grads[n], 1e-3 * gmax)) for n, p in model.named_parameters()),
+                key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst
+    for n, b in model.named_buffers():
+        if n.endswith(("running_mean", "running_var")):
+            assert _rel(b, ref_bufs[n]) < 1e-4, n
+    # ---- optimizer step: fused AdamW on the HIP grads == torch AdamW on the same grads
+    from ptv3_hip.optim import FusedAdamW
+    twin = copy.deepcopy(model)
+    for p, q in zip(model.parameters(), twin.parameters()):
+        q.grad = p.grad.clone()
+    groups = lambda m: [  # noqa: E731  (the fork config's "block" keyword group, offset_keypoint_ptv3.py config)
+        dict(params=[p for n, p in m.named_parameters() if "block" in n], lr=2e-4),
+        dict(params=[p for n, p in m.named_parameters() if "block" not in n])]
+    FusedAdamW(groups(model), lr=2e-3, weight_decay=0.05).step()
+    torch.optim.AdamW(groups(twin), lr=2e-3, weight_decay=0.05).step()
+    for (n, p), q in zip(model.named_parameters(), twin.parameters()):
+        assert (p - q).abs().max().item() < 1e-6, n
+
+
+def test_train_step_bf16_close_to_fp32(dev):
+    """bf16 activations (fp32 master weights, fp32 weight-gradient accumulation) against the fp32 HIP run."""
+    import ptv3_scenes as S
+    cfg = dict(TINY_CFG, drop_path=0.0)
+    torch.manual_seed(1234)
+    m32 = _build(cfg, hidden_dim=32).to(dev).train()
+    m16 = copy.deepcopy(m32)
+    m16.backbone.compute_dtype = torch.bfloat16
+    data = {k: v.to(dev) for k, v in S.make_batch([1500, 1100], in_channels=4, extent=96, seed=3, with_target=6).items()}
+    losses = []
+    for m in (m32, m16):
+        torch.manual_seed(5)
+        out = m(data)
+        out["loss"].backward()
+        losses.append(out["loss"].item())
+    assert abs(losses[0] - losses[1]) < 0.05 * abs(losses[0])
+    num = sum(((p.grad - q.grad) ** 2).sum() for p, q in zip(m32.parameters(), m16.parameters())).sqrt().item()
+    den = sum((p.grad ** 2).sum() for p in m32.parameters()).sqrt().item()
+    assert num / den < 0.25, num / den      # bf16 activations: ~3 significant digits through 15 blocks
+    dot = sum((p.grad * q.grad).sum() for p, q in zip(m32.parameters(), m16.parameters())).item()
+    n16 = sum((q.grad ** 2).sum() for q in m16.parameters()).sqrt().item()
+    assert dot / (den * n16) > 0.98, dot / (den * n16)
+    assert all(q.grad.dtype == torch.float32 for q in m16.parameters())
+
+
+def test_drop_path_statistics(dev):
+    from pointcept.models.utils.hip_layers import DropPath
+    dp = DropPath(0.3).train()
+    x = torch.ones(200000, 8, device=dev, requires_grad=True)
+    torch.manual_seed(0)
+    y = dp(x)
+    rows = y[:, 0]
+    kept = (rows > 0).float().mean().item()
+    assert abs(kept - 0.7) < 0.01
+    assert torch.all((rows == 0) | ((rows - 1 / 0.7).abs() < 1e-6))           # scale_by_keep
+    assert torch.equal((y > 0).all(1), (y > 0).any(1))                         # whole rows dropped (per point)
+    y.sum().backward()
+    assert torch.equal(x.grad, y.detach())
+    assert torch.equal(dp.eval()(x), x)
+
+
+def test_loss_decreases_over_steps(dev):
+    """A few optimizer steps on one batch reduce the loss (end-to-end sanity of the training glue)."""
+    import ptv3_scenes as S
+    from ptv3_hip.optim import FusedAdamW
+    torch.manual_seed(7)
+    model = _build(dict(TINY_CFG, drop_path=0.1), hidden_dim=32).to(dev).train()
+    data = {k: v.to(dev) for k, v in S.make_batch([1200, 800], in_channels=4, extent=96, seed=9, with_target=6).items()}
+    opt = FusedAdamW(model.parameters(), lr=3e-3, weight_decay=0.01)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        out = model(data)
+        out["loss"].backward()
+        opt.step()
+        losses.append(out["loss"].item())
+    assert losses[-1] < 0.8 * losses[0], losses
