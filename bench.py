@@ -74,6 +74,9 @@ def parse():
     ap.add_argument("--kind", default="surface", choices=["surface", "lidar"])
     ap.add_argument("--cpu-sample", type=int, default=100000, help="points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--mode", default="forward", choices=["forward", "train"],
+                    help="forward = the headline metric (default); train = forward + backward + fused AdamW per "
+                         "step, DistributedDataParallel over RCCL when --gpus > 1 (BASELINE configs[3] shape)")
     return ap.parse_args()
 
 
@@ -132,6 +135,68 @@ def cpu_baseline(sd, cfg, model, device, n_points):
              "mode": "fp32"})
 
 
+def train_bench(args, model, device, world, rank, local_rank):
+    """Train step of the fork config: forward + backward (HIP Functions) + fused AdamW; gradients are averaged by
+    DistributedDataParallel over RCCL (one bucketed all-reduce of the 46.2M fp32 gradients, overlapped with
+    backward) when world > 1.  One scene per GPU per step = BASELINE configs[3]'s batch-8-on-8-GPUs shape."""
+    import ptv3_scenes as S
+    from ptv3_hip.optim import FusedAdamW
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.backbone.compute_dtype = dtype
+    model.train()
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], find_unused_parameters=False,
+                                                        gradient_as_bucket_view=True)
+    # the fork's optimizer config: AdamW lr 0.002 wd 0.005, "block" parameters at lr 0.0002
+    groups = [dict(params=[p for n, p in model.named_parameters() if "block" in n], lr=2e-4),
+              dict(params=[p for n, p in model.named_parameters() if "block" not in n])]
+    opt = FusedAdamW(groups, lr=2e-3, weight_decay=5e-3)
+    scenes = [S.make_scene(args.points, 4, None, seed, args.kind) for seed in rank_scene_seeds(rank, args.scenes)]
+    batch = {k: v.to(device) for k, v in S.collate(scenes, with_target=6).items()}
+    n_points = args.points * args.scenes
+
+    def step():
+        opt.zero_grad(set_to_none=False)
+        out = net(batch)
+        out["loss"].backward()
+        opt.step()
+        return out["loss"]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = reduce_over_ranks(elapsed, device, dist.ReduceOp.MAX)
+    total_points = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "Mpoints/sec PTv3 train step (fwd+bwd+AdamW) @100k pts/scene, 1024-pt window",
+            "value": round(total_points * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"OffsetKeypointPTv3 (PT-v3m1 fork config, 46.2M params) train step, "
+                                   f"{args.scenes} x {args.points}-point synthetic {args.kind} scene(s) per GPU, "
+                                   f"patch 1024, drop_path 0.3, fused AdamW (2 param groups)",
+                       "points_per_gpu": n_points,
+                       "parallelism": f"dp{world} (DDP over RCCL, 184.7 MB fp32 gradient all-reduce)" if world > 1
+                       else "dp1"},
+            "roofline": None, "cpu_baseline": None, "final_loss": float(loss.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +214,8 @@ def main():
     model, sd, cfg = build_model(device)
 
     cpu, parity = None, None
+    if args.mode == "train":
+        return train_bench(args, model, device, world, rank, local_rank)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         cpu, parity = cpu_baseline(sd, cfg, model, device, args.cpu_sample)
 
