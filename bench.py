@@ -157,7 +157,7 @@ def train_bench(args, model, device, world, rank, local_rank):
     n_points = args.points * args.scenes
 
     def step():
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()
         out = net(batch)
         out["loss"].backward()
         opt.step()

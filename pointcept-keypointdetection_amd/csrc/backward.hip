@@ -11,26 +11,40 @@ namespace ptv3 {
 // ------------------------------------------------------------------------------------------------
 // out[j] = sum_s slab[s][j]   (slab order = fixed summation order)
 // ------------------------------------------------------------------------------------------------
+// thread = (one of 16 columns, one of 16 slab lanes): lane z sums slabs z, z+16, ... in order, the 16 lane
+// sums are then added in lane order (fixed tree: deterministic)
 __global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__ slab, int nslab, int64_t n,
                                                        float* __restrict__ out) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
+  __shared__ float red[16][17];
+  const int c = threadIdx.x & 15, z0 = threadIdx.x >> 4;
+  const int64_t j = (int64_t)blockIdx.x * 16 + c;
   float s = 0.f;
-  for (int z = 0; z < nslab; ++z) s += slab[(int64_t)z * n + j];
-  out[j] = s;
+  if (j < n)
+    for (int z = z0; z < nslab; z += 16) s += slab[(int64_t)z * n + j];
+  red[z0][c] = s;
+  __syncthreads();
+  if (z0 == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) t += red[z][c];
+    out[j] = t;
+  }
 }
 
 static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, slab, nslab, n, out);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, s, slab, nslab, n, out);
 }
 
 // ------------------------------------------------------------------------------------------------
 // dW[o][tap][c] = sum_i dY[i][o] * X[nbr[i][tap]][c]          (kvol = 1, nbr = NULL: plain dY^T X)
-// The contraction runs over POINTS, which are the slow axis of both operands, so the fp32 matrix core
-// (v_mfma_f32_16x16x4_f32: one k per lane group) is the natural fit: lane (i, g) feeds dY[r+g][o0+i] and
-// X[src(r+g)][c0+i] straight from global memory, 64 contiguous bytes per lane group, no transposition.
-// bf16 activations are widened on load; products and sums are exact fp32.
-// Workgroup = 64 x 64 output tile over one row chunk (4 waves, 32 x 32 each); chunks -> slabs.
+// The contraction runs over POINTS, the slow axis of both operands, while the matrix core wants the
+// contraction index contiguous per lane.  Each workgroup therefore stages 64-row blocks of dY and of the
+// gathered X through LDS TRANSPOSED ([channel][row]; coalesced 16-byte global loads, element-wise LDS
+// stores), after which lane (i, g) reads its 4 consecutive rows of channel i as one fragment and the same
+// mma16<T> as the forward kernels applies (bf16: v_mfma_f32_16x16x16_bf16, fp32: exact 16x16x4 chain).
+// Workgroup = one (<=64 x <=64) output tile over one row chunk; its 4 waves split the 16-row k-steps of
+// every block and are summed through LDS at the end; row chunks -> fp32 slabs -> ordered sum.
+// The next block's global loads are issued before the current block's MFMAs.
 // ------------------------------------------------------------------------------------------------
 struct TnArgs {
   const void* dy; const void* x; const int32_t* nbr; float* out;
@@ -38,60 +52,126 @@ struct TnArgs {
   int cout, cin, kvol, tiles_c;
 };
 
+constexpr int TN_RB = 64;           // rows per staged block (= 4 waves x one 16-row k-step)
+constexpr int TN_LS = TN_RB + 4;    // LDS row stride in elements (bank spread, keeps 8/16-byte alignment)
+
 template <typename T>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
+  typedef typename Vec4<T>::type V4;
+  __shared__ __attribute__((aligned(16))) T sA[64 * TN_LS];   // [o][row]
+  __shared__ __attribute__((aligned(16))) T sB[64 * TN_LS];   // [c][row]
+  __shared__ float sR[64 * 64];                                // cross-wave reduction
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int to = blockIdx.x / a.tiles_c, tc = blockIdx.x % a.tiles_c;
   const int tap = blockIdx.y;
-  const int o0 = 64 * to + 32 * (wave >> 1), c0 = 64 * tc + 32 * (wave & 1);
+  const int o0 = 64 * to, c0 = 64 * tc;
+  const int nto = (min(64, a.cout - o0) + 15) / 16, ntc = (min(64, a.cin - c0) + 15) / 16;
   const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_chunk;
   const int64_t r1 = r0 + a.rows_per_chunk < a.m ? r0 + a.rows_per_chunk : a.m;
-  const bool ov[2] = {o0 + i < a.cout, o0 + 16 + i < a.cout};
-  const bool cv[2] = {c0 + i < a.cin, c0 + 16 + i < a.cin};
-  f32x4 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; r += 4) {
-    const int64_t row = r + g;
-    const bool rv = row < r1;
-    int64_t src = row;
-    if (a.nbr) src = rv ? a.nbr[row * a.kvol + tap] : -1;
-    const bool sv = rv && src >= 0;
-    float av[2], bv[2];
+    for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging units: 64 rows x 16 four-channel groups per operand = 4 units per thread
+  V4 ra[4], rb[4];
+  auto fetch = [&](int64_t rblk) {
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      av[p] = (rv && ov[p]) ? to_f32<T>(dy[row * a.cout + o0 + 16 * p + i]) : 0.f;
-      bv[p] = (sv && cv[p]) ? to_f32<T>(x[src * a.cin + c0 + 16 * p + i]) : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int unit = threadIdx.x + 256 * u;
+      const int row = unit >> 4, cg = unit & 15;
+      const int64_t r = rblk + row;
+      ra[u] = zero4<T>();
+      rb[u] = zero4<T>();
+      if (r < r1) {
+        if (o0 + 4 * cg < a.cout) ra[u] = *reinterpret_cast<const V4*>(dy + r * a.cout + o0 + 4 * cg);
+        int64_t src = r;
+        if (a.nbr) src = a.nbr[r * a.kvol + tap];
+        if (src >= 0 && c0 + 4 * cg < a.cin) rb[u] = *reinterpret_cast<const V4*>(x + src * a.cin + c0 + 4 * cg);
+      }
+    }
+  };
+  fetch(r0);
+  for (int64_t rblk = r0; rblk < r1; rblk += TN_RB) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int unit = threadIdx.x + 256 * u;
+      const int row = unit >> 4, cg = unit & 15;
+      const T* ea = reinterpret_cast<const T*>(&ra[u]);
+      const T* eb = reinterpret_cast<const T*>(&rb[u]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sA[(4 * cg + e) * TN_LS + row] = ea[e];
+        sB[(4 * cg + e) * TN_LS + row] = eb[e];
+      }
+    }
+    __syncthreads();
+    if (rblk + TN_RB < r1) fetch(rblk + TN_RB);
+    // this wave's k-step: rows 16*wave .. 16*wave+15 of the block
+    V4 fa[4], fb[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p < nto) fa[p] = *reinterpret_cast<const V4*>(sA + (16 * p + i) * TN_LS + 16 * wave + 4 * g);
+      if (p < ntc) fb[p] = *reinterpret_cast<const V4*>(sB + (16 * p + i) * TN_LS + 16 * wave + 4 * g);
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[q], acc[p][q], 0, 0, 0);
+      for (int q = 0; q < 4; ++q)
+        if (p < nto && q < ntc) acc[p][q] = mma16<T>(fa[p], fb[q], acc[p][q]);
+    __syncthreads();
   }
+  // sum the four waves' partial tiles: waves 1..3 hand theirs to wave 0 through LDS, one at a time
   // acc[p][q][r] = dW[o0 + 16p + 4g + r][tap][c0 + 16q + i]
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (p < nto && q < ntc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sR[(16 * p + 4 * g + r) * 64 + 16 * q + i] = acc[p][q][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (p < nto && q < ntc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[p][q][r] += sR[(16 * p + 4 * g + r) * 64 + 16 * q + i];
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
   float* out = a.out + (int64_t)blockIdx.z * a.slab_stride;
   const int64_t ld = (int64_t)a.kvol * a.cin;
 #pragma unroll
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 4; ++p)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 4; ++q)
+      if (p < nto && q < ntc)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int o = o0 + 16 * p + 4 * g + r, c = c0 + 16 * q + i;
-        if (o < a.cout && c < a.cin) out[o * ld + (int64_t)tap * a.cin + c] = acc[p][q][r];
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + 16 * p + 4 * g + r, c = c0 + 16 * q + i;
+          if (o < a.cout && c < a.cin) out[o * ld + (int64_t)tap * a.cin + c] = acc[p][q][r];
+        }
 }
 
-static int64_t tn_chunks(int64_t m, int64_t* rows_per_chunk) {
-  // at most 128 slabs; chunks are multiples of 4 rows (one matrix-core step)
-  int64_t rpc = cdiv(cdiv(m, 128), 4) * 4;
-  if (rpc < 1024) rpc = 1024;
+static int64_t tn_chunks(int64_t m, int cout, int cin, int kvol, int64_t* rows_per_chunk) {
+  // enough workgroups to fill the chip (tiles x taps x chunks >= ~1024) but at most 64 slabs;
+  // chunks are multiples of the 64-row staging block
+  const int64_t tiles = cdiv(cout, 64) * cdiv(cin, 64) * kvol;
+  int64_t want = cdiv(1024, tiles);
+  if (want > 64) want = 64;
+  int64_t rpc = cdiv(cdiv(m, want), TN_RB) * TN_RB;
+  if (rpc < 4 * TN_RB) rpc = 4 * TN_RB;
   *rows_per_chunk = rpc;
   return cdiv(m, rpc);
 }
@@ -137,8 +217,9 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const T* __restrict__ a
 }
 
 static int64_t col_chunks(int64_t m, int64_t* rb) {
+  // up to 256 row chunks (one workgroup each): small levels still spread over the chip
   int64_t r = cdiv(cdiv(m, 256), 4) * 4;
-  if (r < 256) r = 256;
+  if (r < 16) r = 16;
   *rb = r;
   return cdiv(m, r);
 }
@@ -313,7 +394,7 @@ using namespace ptv3;
 
 extern "C" size_t ptv3_gemm_tn_workspace_bytes(int64_t m, int cout, int cin, int kvol) {
   int64_t rpc;
-  const int64_t ns = tn_chunks(m, &rpc);
+  const int64_t ns = tn_chunks(m, cout, cin, kvol, &rpc);
   return ns > 1 ? (size_t)ns * cout * kvol * cin * sizeof(float) : 0;
 }
 
@@ -329,8 +410,9 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
     if (hipMemsetAsync(dw, 0, nw * sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
     return PTV3_OK;
   }
+  PTV3_REQUIRE(cout % 4 == 0 && cin % 4 == 0, "gemm_tn: cout=%d and cin=%d must be multiples of 4", cout, cin);
   int64_t rpc;
-  const int64_t ns = tn_chunks(m, &rpc);
+  const int64_t ns = tn_chunks(m, cout, cin, kvol, &rpc);
   PTV3_REQUIRE(workspace_bytes >= ptv3_gemm_tn_workspace_bytes(m, cout, cin, kvol), "gemm_tn: workspace too small");
   TnArgs a;
   a.dy = dy; a.x = x; a.nbr = nbr;

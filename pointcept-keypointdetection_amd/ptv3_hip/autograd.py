@@ -36,6 +36,7 @@ class LinearFn(Function):
         ctx.save_for_backward(xp, weight)
         ctx.has_bias = bias is not None
         ctx.cin = x.shape[1]
+        ctx.w = w   # the cast copy serves the backward too (one cast per step, not two)
         return ops.gemm(xp, w, bias=None if bias is None else bias.detach().float().contiguous())
 
     @staticmethod
@@ -47,8 +48,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             # dx = dy W : the same GEMM with the transposed weight (cin, cout); cout padded to the K granule
             dyp = _pad_cols(dy, gran)
-            wt = weight.detach().to(dy.dtype).t()
-            wt = _pad_cols(wt.contiguous(), gran)
+            wt = _pad_cols(ctx.w[:, :ctx.cin].t().contiguous(), gran)
             dx = ops.gemm(dyp, wt)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm_tn(dy, xp)[:, :ctx.cin].to(weight.dtype)

@@ -63,6 +63,16 @@ class FusedAdamW(torch.optim.Optimizer):
         self._nt, self._nb, self._key = len(ent), blocks, key
 
     @torch.no_grad()
+    def zero_grad(self, set_to_none=False):
+        """Default keeps the gradient tensors (stable addresses: the device table is built once) and zeroes
+        them with multi-tensor fills instead of one launch per parameter."""
+        if set_to_none:
+            return super().zero_grad(set_to_none=True)
+        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if grads:
+            torch._foreach_zero_(grads)
+
+    @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = None
         if closure is not None:
