@@ -296,6 +296,25 @@ int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const
 int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws, float* out,
                      void* stream);
 
+/* ---- keypoint aggregation (the step after the model) -------------------------------------------------
+ * One launch for the per-sample x per-keypoint python loops of engines/hooks/offset_keypoint_evaluator.py:46-84
+ * and tools/infer_offset.py:555-597.  coord (N,3) fp32; pred (N, nkp, 4) fp32 = [offset xyz, score] (model output
+ * or target); offset (nscenes) cumulative int64; scale (nscenes) / centroid (nscenes,3) fp32 or NULL (1 / 0).
+ * point(i) = coord[i]*scale + centroid + pred[i][k][0:3]*scale  (each step rounded as the torch statements).
+ *   PTV3_KP_ARGMAX    kp = point(first arg max of the score)                    aux = that index within the scene
+ *   PTV3_KP_WEIGHTED  kp = sum w point / sum w over score > thresh, arg max if none (infer_offset "weighted")
+ *                                                                               aux = # points over thresh
+ *   PTV3_KP_GT_MEAN   kp = mean of point(i) over score > 0 (evaluator :49-53)   aux = # such points, NaN if 0
+ *   PTV3_KP_GT_FIRST  kp = point(first i with score > 0.5) (infer_offset :592-596)  aux = that index or -1 (NaN)
+ * kp_out (nscenes, nkp, 3) fp32, aux_out (nscenes, nkp) int32. */
+#define PTV3_KP_ARGMAX 0
+#define PTV3_KP_WEIGHTED 1
+#define PTV3_KP_GT_MEAN 2
+#define PTV3_KP_GT_FIRST 3
+int ptv3_keypoint_aggregate(const float* coord, const float* pred, const int64_t* offset, int nscenes, int nkp,
+                            const float* scale, const float* centroid, int mode, float thresh, float* kp_out,
+                            int32_t* aux_out, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------------
  * While enabled, ptv3_gemm and ptv3_window_attn_fwd bracket their launches with HIP events on the launch
  * stream.  collect() synchronises the device and returns, per kernel family (0 linear, 1 subm_conv,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
     "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P]),
     "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P]),
+    "ptv3_keypoint_aggregate": (c_int, [P, P, P, c_int, c_int, P, P, c_int, c_float, P, P, P]),
     "ptv3_profile_enable": (c_int, [c_int]),
     "ptv3_profile_collect": (c_int, [P, P, P, P]),
     "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),

@@ -486,6 +486,31 @@ def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, s
 
 
 # ---------------------------------------------------------------------------------------------
+# keypoint aggregation (after the model)
+# ---------------------------------------------------------------------------------------------
+KP_ARGMAX, KP_WEIGHTED, KP_GT_MEAN, KP_GT_FIRST = 0, 1, 2, 3
+
+
+def keypoint_aggregate(coord, pred, offset, mode, scale=None, centroid=None, thresh=0.5):
+    """(B, K, 3) keypoints + (B, K) int32 aux per scene and keypoint; see ptv3_keypoint_aggregate."""
+    _chk(coord, "coord", torch.float32, 2)
+    _chk(pred, "pred", torch.float32, 3)
+    _chk(offset, "offset", torch.int64, 1)
+    _chk(scale, "scale", torch.float32, 1)
+    _chk(centroid, "centroid", torch.float32, 2)
+    n, k, four = pred.shape
+    b = offset.shape[0]
+    if four != 4 or coord.shape != (n, 3) or (scale is not None and scale.shape[0] != b) or \
+            (centroid is not None and tuple(centroid.shape) != (b, 3)):
+        raise RuntimeError("keypoint_aggregate: shape mismatch")
+    kp = torch.empty((b, k, 3), dtype=torch.float32, device=coord.device)
+    aux = torch.empty((b, k), dtype=torch.int32, device=coord.device)
+    lib.check(lib.ptv3_keypoint_aggregate(_p(coord), _p(pred), _p(offset), b, k, _p(scale), _p(centroid), int(mode),
+                                          float(thresh), _p(kp), _p(aux), _stream()), "ptv3_keypoint_aggregate")
+    return kp, aux
+
+
+# ---------------------------------------------------------------------------------------------
 # pointops
 # ---------------------------------------------------------------------------------------------
 def knn_query(nsample, xyz, offset, new_xyz, new_offset):

@@ -509,3 +509,78 @@ def test_fork_config_vs_oracle(dev, sizes, kind, extent):
         out16 = model({k: v.to(dev) for k, v in data.items()})
     rel = (out16["pred"].cpu() - ref["pred"]).abs().mean().item() / ref["pred"].abs().mean().item()
     assert rel < 0.1, rel
+
+
+# ------------------------------------------------------------------------------------------------
+# keypoint aggregation (evaluator hook / infer_offset post-step)
+# ------------------------------------------------------------------------------------------------
+def _kp_case(seed, sizes, K=6, empty_kp=True):
+    g = torch.Generator().manual_seed(seed)
+    n = sum(sizes)
+    coord = torch.randn(n, 3, generator=g)
+    pred = torch.randn(n, K, 4, generator=g) * 0.2
+    pred[..., 3] = torch.rand(n, K, generator=g)
+    target = torch.randn(n, K, 4, generator=g) * 0.2
+    target[..., 3] = (torch.rand(n, K, generator=g) > 0.9).float()
+    if empty_kp:
+        target[: sizes[0], 2, 3] = 0      # keypoint 2 has no valid point in scene 0
+        pred[: sizes[0], 1, 3] = 0.1      # keypoint 1 never passes the weighted threshold in scene 0
+    offset = torch.tensor(sizes).cumsum(0)
+    scale = torch.rand(len(sizes), generator=g) + 0.5
+    centroid = torch.randn(len(sizes), 3, generator=g)
+    return coord, pred, target, offset, scale, centroid
+
+
+@pytest.mark.parametrize("sizes", [[700, 1300, 50], [5000], [1, 2, 300]])
+def test_keypoint_aggregate_vs_reference_loops(dev, sizes):
+    from ptv3_hip import ops
+    from oracle import keypoints as KO
+    coord, pred, target, offset, scale, centroid = _kp_case(len(sizes), sizes)
+    d = lambda t: t.to(dev)  # noqa: E731
+    for method, mode in (("argmax", ops.KP_ARGMAX), ("weighted", ops.KP_WEIGHTED)):
+        ref_p, ref_t = KO.infer_keypoints(pred, target, coord, offset, scale, centroid, 6, method, 0.5)
+        kp, _ = ops.keypoint_aggregate(d(coord), d(pred), d(offset), mode, d(scale), d(centroid), 0.5)
+        if method == "argmax":
+            assert torch.equal(kp.cpu(), ref_p)                      # same fp32 statements: bit-exact
+        else:
+            assert (kp.cpu() - ref_p).abs().max().item() < 1e-5
+        gt, idx = ops.keypoint_aggregate(d(coord), d(target), d(offset), ops.KP_GT_FIRST, d(scale), d(centroid))
+        assert torch.equal(torch.isnan(gt.cpu()), torch.isnan(ref_t))
+        assert torch.equal(torch.nan_to_num(gt.cpu()), torch.nan_to_num(ref_t))
+        assert torch.equal(idx.cpu() < 0, torch.isnan(ref_t[..., 0]))
+    # evaluator totals (hook): one device vector vs the reference's python accumulation
+    from pointcept.engines.hooks.offset_keypoint_evaluator import evaluate_batch
+    ref = torch.tensor(KO.evaluator_totals(pred, target, coord, offset, scale, 6))
+    got = evaluate_batch(d(pred), d(target), d(coord), d(offset), d(scale)).cpu()
+    assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[8:], ref[8:])   # sample / per-keypoint counts exact
+
+
+def test_offset_keypoint_evaluator_hook(dev):
+    """The hook's own flow (eval loop, totals, logging, SaveBest metric) with a stub trainer."""
+    from pointcept.engines.hooks.builder import HOOKS
+    from oracle import keypoints as KO
+    import types
+    coord, pred, target, offset, scale, _ = _kp_case(5, [400, 600])
+    hook = HOOKS.build(dict(type="OffsetKeypointEvaluator", num_keypoints=6))
+    logs, scalars = [], {}
+    trainer = types.SimpleNamespace(
+        val_loader=[dict(coord=coord, target=target, offset=offset, scale=scale, _pred=pred)],
+        model=None, logger=types.SimpleNamespace(info=logs.append),
+        writer=types.SimpleNamespace(add_scalar=lambda k, v, e: scalars.__setitem__(k, v)), epoch=0, comm_info={})
+
+    class M:
+        def eval(self):
+            return self
+
+        def __call__(self, d):
+            return {"pred": d["_pred"]}
+    trainer.model = M()
+    hook.trainer = trainer
+    hook.after_epoch()
+    ref = KO.evaluator_totals(pred, target, coord, offset, scale, 6)
+    mean = ref[0] / (ref[1] + 1e-6)
+    assert abs(trainer.comm_info["current_metric_value"] + mean) < 1e-4
+    assert trainer.comm_info["current_metric_name"] == "mean_dist"
+    assert abs(scalars["val/MeanDist"] - mean) < 1e-4 and "val/KP_5_MeanDist" in scalars
+    assert any("Keypoint 3 Mean Distance" in s for s in logs)
