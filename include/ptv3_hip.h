@@ -50,7 +50,8 @@ int ptv3_sfc_encode(const void* grid_coord, int coord_is_i64, const int64_t* bat
 /* replaces torch.argsort + scatter_ of arange in Point.serialization
  * (models/utils/structure.py:92-99) and SerializedPooling (point_transformer_v3m1_base.py:399-406):
  * per row r: order[r] = stable argsort(code[r]); inverse[r][order[r][i]] = i.
- * code: (k,n) non-negative int64 with all set bits below `end_bit`; order/inverse: (k,n) int64.
+ * code: (k,n) int64 compared as UNSIGNED 64-bit with all set bits below `end_bit` (<= 64; serialization codes
+ * are non-negative, the GridSample voxel hashes use all 64 bits); order/inverse: (k,n) int64.
  * workspace: ptv3_argsort_workspace_bytes(k,n) bytes. */
 size_t ptv3_argsort_workspace_bytes(int k, int64_t n);
 int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_bit, int64_t* order,
@@ -295,6 +296,18 @@ int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const
                     float grad_scale, void* stream);
 int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws, float* out,
                      void* stream);
+
+/* ---- GridSample (the step before the model) -----------------------------------------------------------
+ * Front half of pointcept/datasets/transform.py:848-860 for one cloud: grid_coord = floor(coord / grid_size)
+ * evaluated in float64 as numpy does (float32 coord / float64 grid size), minus its per-axis minimum; key = the
+ * reference's voxel hash of the shifted coordinate (:926-964).  coord (n,3) fp32; grid_coord (n,3) int64 out;
+ * min_max (6) int64 out = [min xyz, max xyz] of the unshifted voxel coordinate; key (n) uint64 out.
+ * The rest of GridSample composes existing entry points: ptv3_argsort_i64(key, end_bit 64) = np.argsort,
+ * ptv3_pool_segments(key, order, shift 0) = np.unique(return_inverse, return_counts). */
+#define PTV3_HASH_FNV 0
+#define PTV3_HASH_RAVEL 1
+int ptv3_grid_hash(const float* coord, int64_t n, double grid_size, int hash_type, int64_t* grid_coord,
+                   int64_t* min_max, uint64_t* key, void* stream);
 
 /* ---- keypoint aggregation (the step after the model) -------------------------------------------------
  * One launch for the per-sample x per-keypoint python loops of engines/hooks/offset_keypoint_evaluator.py:46-84

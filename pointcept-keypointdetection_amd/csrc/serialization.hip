@@ -353,7 +353,7 @@ extern "C" size_t ptv3_argsort_workspace_bytes(int k, int64_t n) {
 
 extern "C" int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_bit, int64_t* order,
                                 int64_t* inverse, void* workspace, size_t workspace_bytes, void* stream) {
-  PTV3_REQUIRE(end_bit >= 1 && end_bit <= 63, "argsort: end_bit %d outside [1,63]", end_bit);
+  PTV3_REQUIRE(end_bit >= 1 && end_bit <= 64, "argsort: end_bit %d outside [1,64]", end_bit);
   PTV3_REQUIRE(n < (1ll << 31), "argsort: n too large");
   PTV3_REQUIRE(workspace_bytes >= ptv3_argsort_workspace_bytes(k, n), "argsort: workspace too small");
   if (n == 0 || k == 0) return PTV3_OK;

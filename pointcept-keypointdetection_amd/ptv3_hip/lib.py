@@ -1,7 +1,7 @@
 """Loads lib/libptv3_hip.so and declares the C ABI of include/ptv3_hip.h for ctypes."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 PTV3_F32, PTV3_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -62,6 +62,7 @@ SIGNATURES = {
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
     "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P]),
     "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P]),
+    "ptv3_grid_hash": (c_int, [P, c_int64, c_double, c_int, P, P, P, P]),
     "ptv3_keypoint_aggregate": (c_int, [P, P, P, c_int, c_int, P, P, c_int, c_float, P, P, P]),
     "ptv3_profile_enable": (c_int, [c_int]),
     "ptv3_profile_collect": (c_int, [P, P, P, P]),

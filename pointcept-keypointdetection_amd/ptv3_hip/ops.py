@@ -486,6 +486,34 @@ def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, s
 
 
 # ---------------------------------------------------------------------------------------------
+# GridSample (before the model)
+# ---------------------------------------------------------------------------------------------
+HASH_FNV, HASH_RAVEL = 0, 1
+
+
+def grid_hash(coord, grid_size, hash_type=HASH_FNV):
+    """-> grid_coord (n,3) int64 (minimum subtracted), min_max (6) int64, key (n) int64 holding the uint64 hash."""
+    _chk(coord, "coord", torch.float32, 2)
+    n = coord.shape[0]
+    grid = torch.empty((n, 3), dtype=torch.int64, device=coord.device)
+    mm = torch.empty(6, dtype=torch.int64, device=coord.device)
+    key = torch.empty(n, dtype=torch.int64, device=coord.device)
+    lib.check(lib.ptv3_grid_hash(_p(coord), n, float(grid_size), int(hash_type), _p(grid), _p(mm), _p(key), _stream()),
+              "ptv3_grid_hash")
+    return grid, mm, key
+
+
+def voxel_unique(key):
+    """np.argsort + np.unique(return_inverse, return_counts) of the voxel keys on the device:
+    idx_sort (n) int64 (stable), inverse (n) int64 in ORIGINAL point order, seg_start (nvox+1) int32, nvox."""
+    _chk(key, "key", torch.int64, 1)
+    order, _ = argsort_codes(key.view(1, -1), 64)
+    order = order[0].contiguous()
+    cluster, seg_start, nvox = pool_segments(key, order, 0)
+    return order, cluster, seg_start, nvox
+
+
+# ---------------------------------------------------------------------------------------------
 # keypoint aggregation (after the model)
 # ---------------------------------------------------------------------------------------------
 KP_ARGMAX, KP_WEIGHTED, KP_GT_MEAN, KP_GT_FIRST = 0, 1, 2, 3

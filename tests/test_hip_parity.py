@@ -584,3 +584,76 @@ def test_offset_keypoint_evaluator_hook(dev):
     assert trainer.comm_info["current_metric_name"] == "mean_dist"
     assert abs(scalars["val/MeanDist"] - mean) < 1e-4 and "val/KP_5_MeanDist" in scalars
     assert any("Keypoint 3 Mean Distance" in s for s in logs)
+
+
+# ------------------------------------------------------------------------------------------------
+# GridSample on the device (the step before the model)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ci", [0, 1, 2, 3])
+def test_gridsample_device_vs_oracle_and_reference(dev, golden_dir, ci):
+    from ptv3_hip import ops
+    from oracle import gridsample as GS
+    from pointcept.datasets import TRANSFORMS
+    g = _g(golden_dir, "gridsample.npz")
+    t = f"c{ci}_"
+    coord, gs, hash_type = g[t + "coord"], float(g[t + "grid_size"]), str(g[t + "hash"])
+    p = GS.grid_sample_plan(coord, gs, hash_type)
+    # kernel level: voxel coordinates, keys, stable key order, unique - all integer, bit-exact
+    grid, mm, key = ops.grid_hash(torch.from_numpy(coord).to(dev), gs, ops.HASH_FNV if hash_type == "fnv" else ops.HASH_RAVEL)
+    assert np.array_equal(grid.cpu().numpy(), p["grid"])
+    assert np.array_equal(key.cpu().numpy().view(np.uint64), p["key"])
+    idx_sort, inverse, seg_start, nvox = ops.voxel_unique(key)
+    assert np.array_equal(idx_sort.cpu().numpy(), p["idx_sort"])
+    assert np.array_equal(inverse.cpu().numpy(), p["inverse"]) and nvox == len(p["count"])
+    assert np.array_equal(np.diff(seg_start.cpu().numpy()), p["count"])
+    # transform level, train mode: same numpy RNG draw -> same pick as the stable-sort restatement
+    tr = TRANSFORMS.build(dict(type="GridSample", grid_size=gs, hash_type=hash_type, mode="train", return_inverse=True,
+                               return_grid_coord=True, return_min_coord=True, return_displacement=True))
+    feat = np.arange(len(coord), dtype=np.float32)[:, None] * np.ones((1, 2), np.float32)
+    np.random.seed(100 + ci)
+    out = tr(dict(coord=coord.copy(), color=feat.copy(), index_valid_keys=["coord", "color"]))
+    np.random.seed(100 + ci)
+    rand = np.random.randint(0, p["count"].max(), p["count"].size)
+    ref = GS.grid_sample_train(coord, gs, hash_type, rand)
+    assert np.array_equal(out["color"][:, 0].long().cpu().numpy(), ref["idx_unique"])
+    assert np.array_equal(out["coord"].cpu().numpy(), coord[ref["idx_unique"]])
+    assert np.array_equal(out["inverse"].cpu().numpy(), ref["inverse"])
+    assert np.array_equal(out["displacement"].cpu().numpy(), ref["displacement"])
+    # against the reference's own run (order-of-equal-keys independent outputs)
+    assert np.array_equal(out["grid_coord"].cpu().numpy(), g[t + "train_grid_coord"])
+    assert np.array_equal(out["inverse"].cpu().numpy(), g[t + "train_inverse"])
+    assert np.array_equal(out["min_coord"].cpu().numpy(), g[t + "train_min_coord"])
+    # test mode: count.max() parts, every point covered, part 0 = first member of every voxel
+    te = TRANSFORMS.build(dict(type="GridSample", grid_size=gs, hash_type=hash_type, mode="test", return_grid_coord=True))
+    parts = te(dict(coord=coord.copy(), color=feat.copy(), index_valid_keys=["coord", "color"]))
+    assert len(parts) == int(g[t + "test_nparts"])
+    cover = torch.unique(torch.cat([q["index"] for q in parts])).cpu().numpy()
+    assert np.array_equal(cover, g[t + "test_cover"])
+    assert np.array_equal(parts[0]["grid_coord"].cpu().numpy(), g[t + "test_grid_coord"])
+
+
+def test_gridsample_collect_collate_feed_the_model(dev):
+    """GridSample -> Collect -> point_collate_fn on the device produces the dict the model consumes (A0)."""
+    from pointcept.datasets import TRANSFORMS, point_collate_fn
+    rng = np.random.default_rng(3)
+    samples = []
+    for n in (4000, 2500):
+        coord = rng.normal(size=(n, 3)).astype(np.float32)
+        coord /= np.abs(coord).max()
+        d = dict(coord=coord, normal=rng.normal(size=(n, 3)).astype(np.float32),
+                 curvature=rng.random((n, 1)).astype(np.float32), index_valid_keys=["coord", "normal", "curvature"])
+        np.random.seed(n)
+        d = TRANSFORMS.build(dict(type="GridSample", grid_size=0.02, mode="train", return_grid_coord=True))(d)
+        d = TRANSFORMS.build(dict(type="Collect", keys=("coord", "grid_coord"), feat_keys=("coord", "curvature")))(d)
+        samples.append(d)
+    batch = point_collate_fn(samples)
+    assert batch["feat"].shape[1] == 4 and batch["feat"].is_cuda and batch["grid_coord"].dtype == torch.int64
+    assert batch["offset"].tolist() == [samples[0]["coord"].shape[0], samples[0]["coord"].shape[0] + samples[1]["coord"].shape[0]]
+    # voxels are unique per scene after sampling: the model's serialization contract
+    for a, b in zip([0] + batch["offset"].tolist()[:-1], batch["offset"].tolist()):
+        gc = batch["grid_coord"][a:b]
+        assert torch.unique(gc, dim=0).shape[0] == gc.shape[0]
+    model = _build(TINY_CFG, hidden_dim=32).to(dev).eval()
+    with torch.no_grad():
+        out = model({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()})
+    assert out["pred"].shape == (batch["coord"].shape[0], 6, 4) and torch.isfinite(out["pred"]).all()

@@ -108,3 +108,39 @@ def test_full_model_golden(golden_dir):
         assert np.abs(tr[k].numpy() - g["tap_" + k]).max() < 2e-5, k
     assert np.abs(out["pred"].numpy() - g["pred"]).max() < 2e-5
     assert abs(out["loss"].item() - float(g["loss"])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# GridSample restatement vs the reference's own outputs (tests/golden/gridsample.npz)
+# ------------------------------------------------------------------------------------------------
+def _gs_cases(golden_dir):
+    g = np.load(os.path.join(golden_dir, "gridsample.npz"))
+    for ci in range(4):
+        t = f"c{ci}_"
+        yield ci, {k[len(t):]: g[k] for k in g.files if k.startswith(t)}
+
+
+def test_gridsample_oracle_matches_reference(golden_dir):
+    from oracle import gridsample as GS
+    for ci, c in _gs_cases(golden_dir):
+        coord, gs, hash_type = c["coord"], float(c["grid_size"]), str(c["hash"])
+        p = GS.grid_sample_plan(coord, gs, hash_type)
+        nvox = len(p["count"])
+        # everything that does not depend on the order of equal keys is bit-exact
+        assert np.array_equal(p["inverse"], c["train_inverse"]), ci
+        assert np.array_equal(p["min_coord"], c["train_min_coord"]), ci
+        assert nvox == len(c["train_grid_coord"]) == len(c["test_grid_coord"])
+        assert int(c["test_nparts"]) == p["count"].max()
+        assert np.array_equal(c["test_cover"], np.arange(len(coord)))
+        # the reference's selected points: one member of voxel j at position j, grid_coord / displacement of it
+        pid = c["train_point_id"]
+        assert np.array_equal(p["inverse"][pid], np.arange(nvox)), ci
+        assert np.array_equal(p["grid"][pid], c["train_grid_coord"]), ci
+        assert np.array_equal((p["scaled"] - p["grid"] - 0.5)[pid], c["train_displacement"]), ci
+        assert np.array_equal(coord[pid], c["train_coord"]), ci
+        # voxels with one member: the pick itself is determined
+        single = p["count"] == 1
+        rand = np.zeros(nvox, dtype=np.int64)
+        mine = GS.grid_sample_train(coord, gs, hash_type, rand)
+        assert np.array_equal(mine["idx_unique"][single], pid[single]), ci
+        assert np.array_equal(mine["grid_coord"], c["train_grid_coord"]), ci
