@@ -216,12 +216,16 @@ class PTv3Oracle:
                              P["serialized_order"][order_index], P["serialized_inverse"][order_index],
                              pad, unpad, H, K, rpe_table=rpe, grid_coord=P["grid_coord"],
                              patch_size_cfg=patch_size)
+        if name + ".ls1.0.gamma" in sd:     # LayerScale of "PT-v3m2" (v3m2_sonata.py:26-38, 349)
+            x = x * sd[name + ".ls1.0.gamma"]
         feat = shortcut + x
         shortcut = feat
         x = self._ln(feat, name + ".norm2.0")
         x = self._lin(x, name + ".mlp.0.fc1")
         x = F.gelu(x)
         x = self._lin(x, name + ".mlp.0.fc2")
+        if name + ".ls2.0.gamma" in sd:
+            x = x * sd[name + ".ls2.0.gamma"]
         P["feat"] = shortcut + x
         return P
 
@@ -294,6 +298,70 @@ class PTv3Oracle:
                                 self.enc_patch_size[s], i % k)
             self.trace[f"enc{s}"] = P["feat"].clone()
             self.trace[f"n{s}"] = P["feat"].shape[0]
+        if not self.enc_mode:
+            for s in reversed(range(self.num_stages - 1)):
+                P = self._unpool(P, f"dec.dec{s}.up")
+                for i in range(self.dec_depths[s]):
+                    P = self._block(P, f"dec.dec{s}.block{i}", self.dec_channels[s], self.dec_num_head[s],
+                                    self.dec_patch_size[s], i % k)
+                self.trace[f"dec{s}"] = P["feat"].clone()
+        return P
+
+
+class PTv3m2Oracle(PTv3Oracle):
+    """"PT-v3m2" (point_transformer_v3m2_sonata.py:545-732): Linear+LayerNorm+GELU stem, serialization after the
+    stem, GridPooling / GridUnpooling (LayerNorm, re-serialization of every pooled level), LayerScale."""
+
+    # -- GridPooling (:402-470) ------------------------------------------------
+    def _pool(self, P, name, stride):
+        gc = torch.div(P["grid_coord"], stride, rounding_mode="trunc")
+        gc = gc | (P["batch"].view(-1, 1) << 48)
+        gc, cluster, counts = torch.unique(gc, sorted=True, return_inverse=True, return_counts=True, dim=0)
+        gc = gc & ((1 << 48) - 1)
+        _, indices = torch.sort(cluster, stable=True)
+        idx_ptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, dim=0)])
+        head_indices = indices[idx_ptr[:-1]]
+        Q = dict(
+            feat=segment_reduce(self._lin(P["feat"], name + ".proj")[indices], idx_ptr, "max"),
+            coord=segment_reduce(P["coord"][indices], idx_ptr, "mean"),
+            grid_coord=gc, batch=P["batch"][head_indices],
+            pooling_inverse=cluster, pooling_parent=P,
+        )
+        Q["offset"] = torch.cumsum(torch.bincount(Q["batch"]), dim=0).long()
+        Q["feat"] = F.gelu(self._ln(Q["feat"], name + ".norm.0"))
+        self._serialize(Q)
+        return Q
+
+    # -- GridUnpooling (:497-512): sparse_conv_feat IS refreshed here, no stale-skip quirk ---------
+    def _unpool(self, P, name):
+        parent = P.pop("pooling_parent")
+        inverse = P["pooling_inverse"]
+        y = F.gelu(self._ln(self._lin(parent["feat"], name + ".proj_skip.0"), name + ".proj_skip.1"))
+        x = F.gelu(self._ln(self._lin(P["feat"], name + ".proj.0"), name + ".proj.1"))
+        parent["feat"] = y + x[inverse]
+        return parent
+
+    def backbone(self, data):
+        P = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in data.items()}
+        if "batch" not in P:
+            bincount = torch.diff(P["offset"], prepend=torch.zeros(1, dtype=P["offset"].dtype))
+            P["batch"] = torch.arange(len(bincount)).repeat_interleave(bincount)
+        elif "offset" not in P:
+            P["offset"] = torch.cumsum(P["batch"].bincount(), dim=0).long()
+        P["offset"], P["batch"], P["feat"] = P["offset"].long(), P["batch"].long(), P["feat"].float()
+        # Embedding (:505-540): stem on the raw features, THEN serialization (:722-725)
+        x = self._lin(P["feat"], "embedding.stem.linear")
+        P["feat"] = F.gelu(self._ln(x, "embedding.stem.norm"))
+        self.trace["embedding"] = P["feat"].clone()
+        self._serialize(P)
+        k = len(self.order)
+        for s in range(self.num_stages):
+            if s > 0:
+                P = self._pool(P, f"enc.enc{s}.down", self.stride[s - 1])
+            for i in range(self.enc_depths[s]):
+                P = self._block(P, f"enc.enc{s}.block{i}", self.enc_channels[s], self.enc_num_head[s],
+                                self.enc_patch_size[s], i % k)
+            self.trace[f"enc{s}"] = P["feat"].clone()
         if not self.enc_mode:
             for s in reversed(range(self.num_stages - 1)):
                 P = self._unpool(P, f"dec.dec{s}.up")

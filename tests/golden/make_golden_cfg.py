@@ -19,3 +19,13 @@ FORK_CFG = dict(
     attn_drop=0.0, proj_drop=0.0, drop_path=0.3, shuffle_orders=True, pre_norm=True, enable_rpe=False,
     enable_flash=False, upcast_attention=False, upcast_softmax=False,
 )
+
+# "PT-v3m2" (point_transformer_v3m2_sonata.py) plumbing-size config: GridPooling, LayerScale, LayerNorm stem
+TINY_M2_CFG = dict(
+    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
+    enc_depths=(1, 1, 1, 2, 1), enc_channels=(16, 16, 32, 32, 64), enc_num_head=(1, 1, 2, 2, 4),
+    enc_patch_size=(64,) * 5, dec_depths=(1, 1, 1, 1), dec_channels=(16, 16, 32, 32),
+    dec_num_head=(1, 1, 2, 2), dec_patch_size=(64,) * 4, mlp_ratio=4, qkv_bias=True,
+    drop_path=0.3, layer_scale=0.5, shuffle_orders=True, pre_norm=True, enable_rpe=False, enable_flash=False,
+    upcast_attention=False, upcast_softmax=False,
+)

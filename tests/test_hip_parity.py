@@ -657,3 +657,54 @@ def test_gridsample_collect_collate_feed_the_model(dev):
     with torch.no_grad():
         out = model({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in batch.items()})
     assert out["pred"].shape == (batch["coord"].shape[0], 6, 4) and torch.isfinite(out["pred"]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# "PT-v3m2" (GridPooling / LayerScale / LayerNorm stem) - SURVEY 8 f2
+# ------------------------------------------------------------------------------------------------
+def test_v3m2_golden_and_oracle(dev, golden_dir):
+    from pointcept.models import build_model
+    from oracle import ptv3 as O
+    from make_golden_cfg import TINY_M2_CFG
+    import ptv3_scenes as S
+    g = _g(golden_dir, "ptv3m2_tiny.npz")
+    model = build_model(dict(type="PT-v3m2", **TINY_M2_CFG))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    data = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    taps = {}
+
+    def mk(name):
+        def hook(m, i, o):
+            taps[name] = o
+        return hook
+    for s in range(5):
+        getattr(model.enc, f"enc{s}").register_forward_hook(mk(f"enc{s}"))
+    torch.manual_seed(int(g["shuffle_seed"]))
+    with torch.no_grad():
+        point = model(data)
+    for s in range(1, 5):   # pooled geometry: integer outputs bit-exact, mean coordinate to fp32 rounding
+        o = taps[f"enc{s}"]
+        assert np.array_equal(o.grid_coord.cpu().numpy(), g[f"tap_enc{s}_grid_coord"]), s
+        assert np.array_equal(o.batch.cpu().numpy(), g[f"tap_enc{s}_batch"]), s
+        assert np.array_equal(o.serialized_order.cpu().numpy(), g[f"tap_enc{s}_order"]), s
+        assert np.array_equal(o.pooling_inverse.cpu().numpy(), g[f"tap_enc{s}_pooling_inverse"]), s
+        assert (o.coord.cpu() - torch.from_numpy(g[f"tap_enc{s}_coord"])).abs().max().item() < 1e-5
+    assert (point.feat.cpu() - torch.from_numpy(g["feat"])).abs().max().item() < FP32_TOL
+    # a second scene, against the oracle (itself pinned to the reference by test_v3m2_oracle_matches_reference)
+    data2 = S.make_batch([2600, 1900, 700], in_channels=4, extent=80, seed=31)
+    orc = O.PTv3m2Oracle(TINY_M2_CFG, sd)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        ref = orc.backbone(data2)["feat"]
+    torch.manual_seed(3)
+    with torch.no_grad():
+        out = model({k: v.to(dev) for k, v in data2.items()}).feat
+    assert (out.cpu() - ref).abs().max().item() < FP32_TOL
+    # segmentor wrapper of the semseg configs (default.py:41-95): backbone + Linear head
+    seg = build_model(dict(type="DefaultSegmentorV2", num_classes=13, backbone_out_channels=16,
+                           backbone=dict(type="PT-v3m2", **TINY_M2_CFG))).to(dev).eval()
+    with torch.no_grad():
+        logits = seg({k: v.to(dev) for k, v in data2.items()})["seg_logits"]
+    assert logits.shape == (data2["coord"].shape[0], 13) and torch.isfinite(logits).all()

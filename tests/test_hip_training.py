@@ -144,3 +144,34 @@ def test_loss_decreases_over_steps(dev):
         opt.step()
         losses.append(out["loss"].item())
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_v3m2_train_step_vs_oracle_autograd(dev):
+    """"PT-v3m2" (GridPooling, LayerScale, LayerNorm everywhere) forward + backward vs torch autograd on the oracle."""
+    from oracle import ptv3 as O
+    from pointcept.models import build_model
+    from make_golden_cfg import TINY_M2_CFG
+    import ptv3_scenes as S
+    cfg = dict(TINY_M2_CFG, drop_path=0.0)
+    torch.manual_seed(77)
+    model = build_model(dict(type="PT-v3m2", **cfg))
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() > 1:
+                p.mul_(8.0)
+            elif not n.endswith("gamma"):
+                p.add_(torch.randn(p.shape, generator=g) * 0.1)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    data = S.make_batch([1100, 800], in_channels=4, extent=64, seed=8)
+    w = torch.randn(data["coord"].shape[0], cfg["dec_channels"][0], generator=g)
+    orc = O.PTv3m2Oracle(cfg, sd, training=True)
+    torch.manual_seed(5)
+    (orc.backbone(data)["feat"] * w).sum().backward()
+    ref = {k: v.grad for k, v in orc.sd.items() if v.requires_grad}
+    model = model.to(dev).train()
+    torch.manual_seed(5)
+    (model({k: v.to(dev) for k, v in data.items()}).feat * w.to(dev)).sum().backward()
+    gmax = max(v.abs().max().item() for v in ref.values())
+    worst = max(((n, _rel(p.grad, ref[n], 1e-3 * gmax)) for n, p in model.named_parameters()), key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst

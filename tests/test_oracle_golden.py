@@ -144,3 +144,21 @@ def test_gridsample_oracle_matches_reference(golden_dir):
         mine = GS.grid_sample_train(coord, gs, hash_type, rand)
         assert np.array_equal(mine["idx_unique"][single], pid[single]), ci
         assert np.array_equal(mine["grid_coord"], c["train_grid_coord"]), ci
+
+
+def test_v3m2_oracle_matches_reference(golden_dir):
+    """"PT-v3m2" restatement vs the reference's own eval run (tests/golden/ptv3m2_tiny.npz)."""
+    from oracle import ptv3 as O
+    from make_golden_cfg import TINY_M2_CFG
+    g = np.load(os.path.join(golden_dir, "ptv3m2_tiny.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    data = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    orc = O.PTv3m2Oracle(TINY_M2_CFG, sd)
+    torch.manual_seed(int(g["shuffle_seed"]))
+    with torch.no_grad():
+        P = orc.backbone(data)
+    for name in ["embedding"] + [f"enc{s}" for s in range(5)] + [f"dec{s}" for s in (3, 2, 1, 0)]:
+        ref = torch.from_numpy(g["tap_" + name])
+        assert orc.trace[name].shape == ref.shape, name
+        assert (orc.trace[name] - ref).abs().max().item() < 1e-5, name
+    assert (P["feat"] - torch.from_numpy(g["feat"])).abs().max().item() < 1e-5
