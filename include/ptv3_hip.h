@@ -140,6 +140,16 @@ int ptv3_block_fusable(int c, int hidden, int dtype, int64_t m);
 int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias, const void* shortcut,
                     const float* g0, const float* b0, const float* g1, const float* b1, const void* wqkv,
                     const float* bqkv, void* f1, void* qkv, int64_t m, int c, float eps, int dtype, void* stream);
+/* Row-local two-layer MLP, hidden layer in registers (the dense keypoint head, offset_keypoint_ptv3.py:26-31:
+ * Linear -> BatchNorm1d(eval) -> ReLU -> Linear):  out = act((x @ w1^T + b1) * s1 + t1) @ w2^T + b2.
+ * x (m, cin) dtype, cin in {32, 64}; w1 (hidden, cin) natural; b1 / s1 / t1 (hidden) fp32 (each optional: 0 / 1 / 0);
+ * w2 (ceil16(cout), hidden) with zero rows beyond cout and, for bf16, its input channels chain-permuted exactly like
+ * ptv3_block_tail's w2; b2 (cout) fp32; out (m, cout) fp32 when out_f32 else dtype.  hidden % 64 == 0, cout % 4 == 0,
+ * cout <= 64 (ptv3_mlp2_fusable). */
+int ptv3_mlp2_fusable(int cin, int hidden, int cout, int dtype);
+int ptv3_mlp2(const void* x, const void* w1, const float* b1, const float* s1, const float* t1, int act,
+              const void* w2, const float* b2, void* out, int out_f32, int64_t m, int cin, int hidden, int cout,
+              int dtype, void* stream);
 int ptv3_block_tail(const void* attn, const void* f1, const void* wproj, const float* bproj, const float* g2,
                     const float* b2, const void* w1, const float* bias1, const void* w2, const float* bias2,
                     void* out, int64_t m, int c, int hidden, float eps, int dtype, void* stream);
@@ -150,6 +160,12 @@ int ptv3_block_tail(const void* attn, const void* f1, const void* wproj, const f
 int ptv3_layernorm(const void* x, const float* gamma, const float* beta, const void* res, void* y,
                    const float* gamma2, const float* beta2, void* y2, int64_t m, int c, float eps,
                    int dtype, void* stream);
+
+/* same, with x given as the split-K fp32 slabs a ptv3_gemm(out = NULL) left behind: x = T(sum_z slab[z] + slab_bias)
+ * (saves the separate reduce launch and one (m, c) round trip in front of the xCPE LayerNorm, :283) */
+int ptv3_layernorm_slabs(const float* slab, int splits, const float* slab_bias, const float* gamma, const float* beta,
+                         const void* res, void* y, const float* gamma2, const float* beta2, void* y2, int64_t m, int c,
+                         float eps, int dtype, void* stream);
 
 /* y = act(x * scale[c] + shift[c]) : eval BatchNorm1d + GELU of Embedding / SerializedPooling
  * (:508-511, 439-442). In-place allowed. */

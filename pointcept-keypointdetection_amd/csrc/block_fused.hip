@@ -164,7 +164,9 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
   }
 }
 
-template <typename T, int NT>
+// RT = 16-point row tiles per wave: every weight fragment fetched from L1/L2 feeds RT matrix-core steps and the
+// RT chains are independent (the single-tile form is latency-bound: one MFMA per fragment load).
+template <typename T, int NT, int RT>
 __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
@@ -174,10 +176,14 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   constexpr int HKC = 64 / KC;  // K-chunks per 64-wide hidden slice (2 bf16 / 4 fp32)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + li;
-  if (((int64_t)blockIdx.x * 4 + wave) * 16 >= a.m) return;
-  const bool valid = row < a.m;
-  const int64_t rc = valid ? row : a.m - 1;
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+  if (base >= a.m) return;
+  int64_t row[RT], rc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    row[t] = base + 16 * t + li;
+    rc[t] = row[t] < a.m ? row[t] : a.m - 1;
+  }
   const T* attn = reinterpret_cast<const T*>(a.attn);
   const T* f1 = reinterpret_cast<const T*>(a.f1);
   const T* wp = reinterpret_cast<const T*>(a.wproj);
@@ -185,80 +191,200 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   const T* w2 = reinterpret_cast<const T*>(a.w2);
 
   // ---- f2 = attn @ Wproj^T + b + f1   (attn rows are in natural channel order: natural Wproj)
-  f32x4 f2[NT];
+  f32x4 f2[RT][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) f2[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) f2[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int kc = 0; kc < C / KC; ++kc) {
-    FR xb = *reinterpret_cast<const FR*>(attn + rc * C + KC * kc + E * g);
+    FR xb[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) xb[t] = *reinterpret_cast<const FR*>(attn + rc[t] * C + KC * kc + E * g);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       FR wa = *reinterpret_cast<const FR*>(wp + (int64_t)(16 * j + li) * C + KC * kc + E * g);
-      f2[j] = F::mma(wa, xb, f2[j]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) f2[t][j] = F::mma(wa, xb[t], f2[t][j]);
     }
   }
-  f32x4 t5[NT];
+  FR xf[RT][NKC];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int ch = 16 * j + 4 * g;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bproj + ch);
-    float s[4];
-    unpack4<T>(*reinterpret_cast<const V4*>(f1 + rc * C + ch), s);
+  for (int t = 0; t < RT; ++t) {
+    f32x4 t5[NT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) f2[j][r] = round_to<T>(f2[j][r] + b[r] + s[r]);
+    for (int j = 0; j < NT; ++j) {
+      const int ch = 16 * j + 4 * g;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bproj + ch);
+      float s[4];
+      unpack4<T>(*reinterpret_cast<const V4*>(f1 + rc[t] * C + ch), s);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) f2[t][j][r] = round_to<T>(f2[t][j][r] + b[r] + s[r]);
+    }
+    float mean, rstd;
+    row_norm<NT>(f2[t], a.eps, mean, rstd);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = 16 * j + 4 * g;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g2 + ch), bt = *reinterpret_cast<const f32x4*>(a.b2 + ch);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t5[j][r] = round_to<T>((f2[t][j][r] - mean) * rstd * gm[r] + bt[r]);
+    }
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) xf[t][kc] = ChainFrag<T, NT>::get(t5, kc);
   }
-  float mean, rstd;
-  row_norm<NT>(f2, a.eps, mean, rstd);
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int ch = 16 * j + 4 * g;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g2 + ch), bt = *reinterpret_cast<const f32x4*>(a.b2 + ch);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t5[j][r] = round_to<T>((f2[j][r] - mean) * rstd * gm[r] + bt[r]);
-  }
-  FR xf[NKC];
-#pragma unroll
-  for (int kc = 0; kc < NKC; ++kc) xf[kc] = ChainFrag<T, NT>::get(t5, kc);
 
   // ---- out = f2 + fc2(GELU(fc1(t5))) : the hidden layer goes through registers 64 channels at a time
-  f32x4 o[NT];
+  f32x4 o[RT][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int h0 = 0; h0 < a.hidden; h0 += 64) {
-    f32x4 h[4];
+    f32x4 h[RT][4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) h[jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) h[t][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         FR wa = *reinterpret_cast<const FR*>(w1 + (int64_t)(h0 + 16 * jj + li) * C + KC * kc + E * g);
-        h[jj] = F::mma(wa, xf[kc], h[jj]);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) h[t][jj] = F::mma(wa, xf[t][kc], h[t][jj]);
       }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias1 + h0 + 16 * jj + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[jj][r] = round_to<T>(gelu_erf(h[jj][r] + b[r]));
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[t][jj][r] = round_to<T>(gelu_erf(h[t][jj][r] + b[r]));
     }
 #pragma unroll
-    for (int m = 0; m < HKC; ++m) {
-      FR hf = ChainFrag<T, 4>::get(h, m);
+    for (int mm = 0; mm < HKC; ++mm) {
+      FR hf[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) hf[t] = ChainFrag<T, 4>::get(h[t], mm);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        FR wa = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * m + E * g);
-        o[j] = F::mma(wa, hf, o[j]);
+        FR wa = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) o[t][j] = F::mma(wa, hf[t], o[t][j]);
       }
     }
   }
-  if (!valid) return;
   T* out = reinterpret_cast<T*>(a.out);
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int ch = 16 * j + 4 * g;
-    const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias2 + ch);
-    *reinterpret_cast<V4*>(out + row * C + ch) =
-        pack4<T>(o[j][0] + b[0] + f2[j][0], o[j][1] + b[1] + f2[j][1], o[j][2] + b[2] + f2[j][2], o[j][3] + b[3] + f2[j][3]);
+  for (int t = 0; t < RT; ++t) {
+    if (row[t] >= a.m) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int ch = 16 * j + 4 * g;
+      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias2 + ch);
+      *reinterpret_cast<V4*>(out + row[t] * C + ch) =
+          pack4<T>(o[t][j][0] + b[0] + f2[t][j][0], o[t][j][1] + b[1] + f2[t][j][1], o[t][j][2] + b[2] + f2[t][j][2],
+                   o[t][j][3] + b[3] + f2[t][j][3]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-local two-layer MLP with the hidden layer kept in registers (the dense keypoint head,
+// offset_keypoint_ptv3.py:26-31: Linear -> BatchNorm1d -> ReLU -> Linear): per wave 16 points,
+//   h = act((x W1^T + b1) * s1 + t1)  64 hidden channels at a time,  out += h W2^T,  out + b2.
+// The (m, hidden) intermediate (51 MB at 100k points x 256 bf16) never exists.
+// ------------------------------------------------------------------------------------------------
+struct Mlp2Args {
+  const void* x; const void* w1; const float* b1; const float* s1; const float* t1;
+  const void* w2; const float* b2; void* out;
+  int64_t m; int hidden, cout, act, out_f32;
+};
+
+template <typename T, int NTI, int NTO, int RT>
+__global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  typedef typename Vec4<T>::type V4;
+  constexpr int CI = 16 * NTI, E = F::E, KC = F::KC;
+  constexpr int HKC = 64 / KC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+  if (base >= a.m) return;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+  const T* w2 = reinterpret_cast<const T*>(a.w2);
+  int64_t row[RT];
+  FR xf[RT][CI / KC];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    row[t] = base + 16 * t + li;
+    const int64_t rc = row[t] < a.m ? row[t] : a.m - 1;
+#pragma unroll
+    for (int kc = 0; kc < CI / KC; ++kc) xf[t][kc] = *reinterpret_cast<const FR*>(x + rc * CI + KC * kc + E * g);
+  }
+  f32x4 o[RT][NTO];
+#pragma unroll
+  for (int t = 0; t < RT; ++t)
+#pragma unroll
+    for (int j = 0; j < NTO; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int h0 = 0; h0 < a.hidden; h0 += 64) {
+    f32x4 h[RT][4];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) h[t][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < CI / KC; ++kc)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        FR wa = *reinterpret_cast<const FR*>(w1 + (int64_t)(h0 + 16 * jj + li) * CI + KC * kc + E * g);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) h[t][jj] = F::mma(wa, xf[t][kc], h[t][jj]);
+      }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int ch = h0 + 16 * jj + 4 * g;
+      const f32x4 b = a.b1 ? *reinterpret_cast<const f32x4*>(a.b1 + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc = a.s1 ? *reinterpret_cast<const f32x4*>(a.s1 + ch) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 sh = a.t1 ? *reinterpret_cast<const f32x4*>(a.t1 + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = (h[t][jj][r] + b[r]) * sc[r] + sh[r];
+          if (a.act == PTV3_ACT_GELU) v = gelu_erf(v);
+          else if (a.act == PTV3_ACT_RELU) v = fmaxf(v, 0.f);
+          h[t][jj][r] = round_to<T>(v);
+        }
+    }
+#pragma unroll
+    for (int mm = 0; mm < HKC; ++mm) {
+      FR hf[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) hf[t] = ChainFrag<T, 4>::get(h[t], mm);
+#pragma unroll
+      for (int j = 0; j < NTO; ++j) {
+        FR wa = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) o[t][j] = F::mma(wa, hf[t], o[t][j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    if (row[t] >= a.m) continue;
+#pragma unroll
+    for (int j = 0; j < NTO; ++j) {
+      const int ch = 16 * j + 4 * g;
+      if (ch >= a.cout) continue;   // cout is a multiple of 4
+      const f32x4 b = a.b2 ? *reinterpret_cast<const f32x4*>(a.b2 + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 v = f32x4{o[t][j][0] + b[0], o[t][j][1] + b[1], o[t][j][2] + b[2], o[t][j][3] + b[3]};
+      if (a.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + row[t] * a.cout + ch) = v;
+      else *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out) + row[t] * a.cout + ch) = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
   }
 }
 
@@ -502,6 +628,31 @@ __global__ void __launch_bounds__(64 * Coop<C>::NW) block_tail_coop_kernel(TailA
 
 using namespace ptv3;
 
+// two 16-point row tiles per wave once there are enough waves to fill the chip several times over
+static int row_tiles(int64_t m) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("PTV3_FUSED_ROW_TILES"); forced = e ? atoi(e) : 0; }
+  if (forced == 1 || forced == 2) return forced;
+  return m >= 32768 ? 2 : 1;
+}
+
+#define TAIL_LAUNCH(ARGS)                                                                                \
+  {                                                                                                      \
+    const int rt = row_tiles(m);                                                                         \
+    dim3 grid((unsigned)cdiv(m, 64 * rt)), block(256);                                                   \
+    if (dtype == PTV3_F32) {                                                                             \
+      if (c == 32) { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<float, 2, 2>), grid, block, 0, s, ARGS); \
+                     else hipLaunchKernelGGL((block_tail_kernel<float, 2, 1>), grid, block, 0, s, ARGS); } \
+      else { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<float, 4, 2>), grid, block, 0, s, ARGS);   \
+             else hipLaunchKernelGGL((block_tail_kernel<float, 4, 1>), grid, block, 0, s, ARGS); }         \
+    } else {                                                                                             \
+      if (c == 32) { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<__bf16, 2, 2>), grid, block, 0, s, ARGS); \
+                     else hipLaunchKernelGGL((block_tail_kernel<__bf16, 2, 1>), grid, block, 0, s, ARGS); } \
+      else { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<__bf16, 4, 2>), grid, block, 0, s, ARGS);  \
+             else hipLaunchKernelGGL((block_tail_kernel<__bf16, 4, 1>), grid, block, 0, s, ARGS); }        \
+    }                                                                                                    \
+  }
+
 #define FUSED_LAUNCH(KERNEL, ARGS)                                                                     \
   {                                                                                                    \
     dim3 grid((unsigned)cdiv(m, 64)), block(256);                                                      \
@@ -574,6 +725,48 @@ static void launch_tail_coop(const TailArgs& a, hipStream_t s) {
     else FN<__bf16, 512>(ARGS, s);                                         \
   }
 
+extern "C" int ptv3_mlp2_fusable(int cin, int hidden, int cout, int dtype) {
+  return (cin == 32 || cin == 64) && hidden > 0 && hidden % 64 == 0 && cout > 0 && cout % 4 == 0 && cout <= 64 &&
+         (dtype == PTV3_F32 || dtype == PTV3_BF16);
+}
+
+extern "C" int ptv3_mlp2(const void* x, const void* w1, const float* b1, const float* s1, const float* t1, int act,
+                         const void* w2, const float* b2, void* out, int out_f32, int64_t m, int cin, int hidden,
+                         int cout, int dtype, void* stream) {
+  PTV3_REQUIRE(ptv3_mlp2_fusable(cin, hidden, cout, dtype), "mlp2: cin=%d hidden=%d cout=%d not fusable", cin, hidden,
+               cout);
+  PTV3_REQUIRE((s1 == nullptr) == (t1 == nullptr), "mlp2: s1/t1 must come together");
+  if (m == 0) return PTV3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  Mlp2Args a;
+  a.x = x; a.w1 = w1; a.b1 = b1; a.s1 = s1; a.t1 = t1; a.w2 = w2; a.b2 = b2; a.out = out;
+  a.m = m; a.hidden = hidden; a.cout = cout; a.act = act; a.out_f32 = out_f32;
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * hidden * (cin + cout),
+                              ((double)m * cin + (double)hidden * (cin + cout)) * esz + (double)m * cout * (out_f32 ? 4 : esz),
+                              nullptr, 0, 0.0);
+  const int rt = row_tiles(m);
+  dim3 grid((unsigned)cdiv(m, 64 * rt)), block(256);
+  const int nto = cout <= 16 ? 1 : cout <= 32 ? 2 : 4;
+#define MLP2_RT(T, NTI, NTO)                                                                      \
+  if (rt == 2) hipLaunchKernelGGL((mlp2_kernel<T, NTI, NTO, 2>), grid, block, 0, s, a);           \
+  else hipLaunchKernelGGL((mlp2_kernel<T, NTI, NTO, 1>), grid, block, 0, s, a);
+#define MLP2_CASE(T, NTI)                                                                         \
+  if (nto == 1) { MLP2_RT(T, NTI, 1) }                                                            \
+  else if (nto == 2) { MLP2_RT(T, NTI, 2) }                                                       \
+  else { MLP2_RT(T, NTI, 4) }
+  if (dtype == PTV3_F32) {
+    if (cin == 32) { MLP2_CASE(float, 2) } else { MLP2_CASE(float, 4) }
+  } else {
+    if (cin == 32) { MLP2_CASE(__bf16, 2) } else { MLP2_CASE(__bf16, 4) }
+  }
+#undef MLP2_CASE
+#undef MLP2_RT
+  prof_end(prof, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
 extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias,
                                const void* shortcut, const float* g0, const float* b0, const float* g1,
                                const float* b1, const void* wqkv, const float* bqkv, void* f1, void* qkv, int64_t m,
@@ -612,7 +805,7 @@ extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wpr
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * (c + 2.0 * hidden),
                               ((double)m * c * 3 + (double)c * c + 2.0 * c * hidden) * esz, nullptr, 0, 0.0);
   if (mode == 1) {
-    FUSED_LAUNCH(block_tail_kernel, a)
+    TAIL_LAUNCH(a)
   } else {
     COOP_LAUNCH(launch_tail_coop, a)
   }

@@ -227,8 +227,19 @@ struct Run {
       void* t2 = F->alloc(row * C); void* f1 = F->alloc(row * C); void* t3 = F->alloc(row * C);
       void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C); void* f2 = F->alloc(row * C);
       void* t5 = F->alloc(row * C); void* t6 = F->alloc(row * hidden);
-      gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-      RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
+      const int splits = ptv3_gemm_splits(L.n, C, C, 27, d->dtype);
+      if (splits > 1) {
+        // the conv leaves its split-K slabs; the LayerNorm kernel sums them (no separate reduce launch)
+        const size_t wsb = ptv3_gemm_workspace_bytes(L.n, C, C, 27, d->dtype);
+        float* slab = (float*)F->alloc(wsb);
+        RUN(ptv3_gemm(L.conv_feat, conv_w, nullptr, L.n, C, C, 27, L.nbr3, L.row_order, nullptr, nullptr, nullptr, 0,
+                      nullptr, nullptr, nullptr, d->dtype, slab, wsb, sf));
+        RUN(ptv3_layernorm_slabs(slab, splits, conv_b, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps,
+                                 d->dtype, sf));
+      } else {
+        gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+        RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
+      }
       gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
       RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
       gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
@@ -433,6 +444,14 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
     const float* bns = (const float*)R.next(); const float* bnt = (const float*)R.next();
     const void* w1 = R.next(); const float* b1 = (const float*)R.next();
     const size_t mark = F.off;
+    if (ptv3_mlp2_fusable(L.channels, d->head_hidden, d->head_out, d->dtype)) {
+      // w1 arrives chain-permuted and row-padded (ptv3_hip/engine.py packs it by the same predicate)
+      if (!dry && R.ok()) {
+        int r = ptv3_mlp2(L.feat, w0, b0, bns, bnt, PTV3_ACT_RELU, w1, b1, io->out_head, 1, L.n, L.channels,
+                          d->head_hidden, d->head_out, d->dtype, sf);
+        if (r) R.rc = r;
+      }
+    } else {
     void* hid = F.alloc((size_t)L.n * d->head_hidden * es);
     R.gemm(L.feat, w0, hid, L.n, L.channels, d->head_hidden, 1, nullptr, nullptr, b0, bns, bnt, PTV3_ACT_RELU, nullptr,
            nullptr, nullptr);
@@ -444,6 +463,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
       R.gemm(hid, w1, o, L.n, d->head_hidden, d->head_out, 1, nullptr, nullptr, b1, nullptr, nullptr, 0, nullptr,
              nullptr, nullptr);
       if (!dry && R.ok()) { int r = ptv3_cast(o, PTV3_BF16, io->out_head, PTV3_F32, L.n * d->head_out, sf); if (r) R.rc = r; }
+    }
     }
     F.off = mark;
   }

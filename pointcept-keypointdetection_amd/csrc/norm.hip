@@ -19,7 +19,8 @@ template <typename T, int LPR>
 __global__ void __launch_bounds__(256)
 layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                  const T* __restrict__ res, T* __restrict__ y, const float* __restrict__ gamma2,
-                 const float* __restrict__ beta2, T* __restrict__ y2, int64_t m, int c, float eps) {
+                 const float* __restrict__ beta2, T* __restrict__ y2, int64_t m, int c, float eps,
+                 const float* __restrict__ slab, int splits, const float* __restrict__ slab_bias) {
   typedef typename Vec4<T>::type V4;
   constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -34,7 +35,16 @@ layernorm_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const
     int ch = sub + k * LPR;
     v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
     if (rv && ch < nch) {
-      unpack4<T>(*reinterpret_cast<const V4*>(x + row * c + 4 * ch), v[k]);
+      if (slab) {
+        // the producing GEMM left split-K fp32 slabs: sum them in slab order, add its bias, round to T as the
+        // separate reduce kernel would have stored it
+        f32x4 acc = *reinterpret_cast<const f32x4*>(slab_bias + 4 * ch);
+        for (int z = 0; z < splits; ++z)
+          acc += *reinterpret_cast<const f32x4*>(slab + ((int64_t)z * m + row) * c + 4 * ch);
+        unpack4<T>(pack4<T>(acc[0], acc[1], acc[2], acc[3]), v[k]);
+      } else {
+        unpack4<T>(*reinterpret_cast<const V4*>(x + row * c + 4 * ch), v[k]);
+      }
       s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
     }
   }
@@ -124,7 +134,7 @@ __global__ void cast_kernel(const S* __restrict__ x, D* __restrict__ y, int64_t 
 template <typename T>
 static int launch_ln(const void* x, const float* gamma, const float* beta, const void* res, void* y,
                      const float* gamma2, const float* beta2, void* y2, int64_t m, int c, float eps,
-                     hipStream_t s) {
+                     hipStream_t s, const float* slab = nullptr, int splits = 0, const float* slab_bias = nullptr) {
   const int nch = c / 4;
   int lpr = 1;
   while (lpr < 64 && lpr < nch) lpr <<= 1;
@@ -132,7 +142,8 @@ static int launch_ln(const void* x, const float* gamma, const float* beta, const
   {                                                                                                      \
     int64_t rows_per_block = 4 * (64 / L);                                                               \
     hipLaunchKernelGGL((layernorm_kernel<T, L>), dim3((unsigned)cdiv(m, rows_per_block)), dim3(256), 0, s, \
-                       (const T*)x, gamma, beta, (const T*)res, (T*)y, gamma2, beta2, (T*)y2, m, c, eps); \
+                       (const T*)x, gamma, beta, (const T*)res, (T*)y, gamma2, beta2, (T*)y2, m, c, eps, slab,   \
+                       splits, slab_bias);                                                                \
   }
   switch (lpr) {
     case 1: LN_LAUNCH(1) break;
@@ -161,6 +172,22 @@ extern "C" int ptv3_layernorm(const void* x, const float* gamma, const float* be
   if (m == 0) return PTV3_OK;
   if (dtype == PTV3_F32) return launch_ln<float>(x, gamma, beta, res, y, gamma2, beta2, y2, m, c, eps, (hipStream_t)stream);
   return launch_ln<__bf16>(x, gamma, beta, res, y, gamma2, beta2, y2, m, c, eps, (hipStream_t)stream);
+}
+
+extern "C" int ptv3_layernorm_slabs(const float* slab, int splits, const float* slab_bias, const float* gamma,
+                                    const float* beta, const void* res, void* y, const float* gamma2,
+                                    const float* beta2, void* y2, int64_t m, int c, float eps, int dtype,
+                                    void* stream) {
+  PTV3_REQUIRE(c > 0 && c % 4 == 0 && c <= 64 * LN_MAXCH * 4, "layernorm_slabs: c=%d must be a multiple of 4, <= 2048", c);
+  PTV3_REQUIRE(slab && slab_bias && splits >= 1, "layernorm_slabs: slab, slab_bias and splits >= 1 are required");
+  PTV3_REQUIRE((y2 == nullptr) || (gamma2 && beta2), "layernorm_slabs: y2 needs gamma2/beta2");
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "layernorm_slabs: bad dtype");
+  if (m == 0) return PTV3_OK;
+  if (dtype == PTV3_F32)
+    return launch_ln<float>(nullptr, gamma, beta, res, y, gamma2, beta2, y2, m, c, eps, (hipStream_t)stream, slab, splits,
+                            slab_bias);
+  return launch_ln<__bf16>(nullptr, gamma, beta, res, y, gamma2, beta2, y2, m, c, eps, (hipStream_t)stream, slab, splits,
+                           slab_bias);
 }
 
 extern "C" int ptv3_affine_act(const void* x, const float* scale, const float* shift, int act, void* y,

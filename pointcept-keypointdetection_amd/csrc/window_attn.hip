@@ -7,6 +7,7 @@
 // Reference semantics: SerializedAttention.forward, point_transformer_v3m1_base.py:184-216.
 #include <type_traits>
 #include "common.h"
+#include <stdlib.h>
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
 
@@ -473,8 +474,14 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
   if (lds_full <= 160 * 1024) {
     // queries per workgroup: 8 waves (512 queries at head_dim 16) when there are plenty of windows, fewer
     // waves per workgroup when the grid would otherwise leave CUs idle
+    static int min_waves = 0;
+    if (!min_waves) {
+      const char* e = getenv("PTV3_ATTN_MIN_WAVES");
+      min_waves = e ? atoi(e) : 4;
+      if (min_waves != 1 && min_waves != 2 && min_waves != 4 && min_waves != 8) min_waves = 4;
+    }
     int waves = 8;
-    while (waves > 4 && (int64_t)nwin * H * ((K + waves * QT * 16 - 1) / (waves * QT * 16)) < 512) waves >>= 1;
+    while (waves > min_waves && (int64_t)nwin * H * ((K + waves * QT * 16 - 1) / (waves * QT * 16)) < 512) waves >>= 1;
     const int QB = waves * QT * 16;
     const int qsplit = (K + QB - 1) / QB;
     if (!attr_set) {

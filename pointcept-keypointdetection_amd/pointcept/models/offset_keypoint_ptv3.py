@@ -43,8 +43,14 @@ class OffsetKeypointPTv3(nn.Module):
         else:
             feat = point_output.feat
             scale, shift = self.head[1].folded()
-            hidden = self.head[0](feat, bn_scale=scale, bn_shift=shift, act=ops.ACT_RELU)
-            pred_flat = self.head[3](hidden).float()
+            h0, h3 = self.head[0], self.head[3]
+            if ops.mlp2_fusable(h0.in_features, h0.out_features, h3.out_features, feat.dtype):
+                w2 = h3._cache.get(("mlp2", feat.dtype), [h3.weight], lambda: ops.mlp2_weight2(h3.weight, feat.dtype))
+                pred_flat = ops.mlp2(feat, h0.weight_for(feat.dtype), h0.bias_f32(), scale, shift, ops.ACT_RELU, w2,
+                                     h3.bias_f32(), h3.out_features)
+            else:
+                hidden = h0(feat, bn_scale=scale, bn_shift=shift, act=ops.ACT_RELU)
+                pred_flat = h3(hidden).float()
         pred = pred_flat.view(-1, self.num_keypoints, 4)
 
         result_dict = {}

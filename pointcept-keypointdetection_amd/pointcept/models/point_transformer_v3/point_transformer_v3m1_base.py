@@ -266,11 +266,16 @@ class Block(PointModule):
         shortcut = point.feat
         spt = point.sparse_conv_feat                         # xCPE conv reads the sparse tensor's features
         wf, bf = self.folded_cpe(spt.features.dtype)
-        x = ops.gemm(spt.features, wf, bias=bf, nbr=spt.neighbors(3, self.cpe[0].indice_key), kvol=27,
-                     row_order=spt.row_order)
+        nbr = spt.neighbors(3, self.cpe[0].indice_key)
         g1, b1 = self.cpe[2].affine_f32()
         g2, b2 = self.norm1[0].affine_f32()
-        feat, x = ops.layernorm(x, g1, b1, self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)
+        slabs = ops.conv_slabs(spt.features, wf, nbr, 27, spt.row_order)
+        if slabs is not None:   # deep levels: the conv splits over K; the LayerNorm kernel sums the slabs
+            feat, x = ops.layernorm_slabs(slabs[0], slabs[1], nbr.shape[0], wf.shape[0], bf, spt.features.dtype, g1, b1,
+                                          self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)
+        else:
+            x = ops.gemm(spt.features, wf, bias=bf, nbr=nbr, kvol=27, row_order=spt.row_order)
+            feat, x = ops.layernorm(x, g1, b1, self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)
         qkv = self.attn.qkv(x)
         x = self.attn.attention_core(point, qkv)
         feat = self.attn.proj(x, res=feat)                  # + shortcut

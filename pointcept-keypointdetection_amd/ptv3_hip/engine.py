@@ -110,7 +110,11 @@ class Packed:
                     i += 1
         if self.head is not None:
             h = self.head
-            t += [self._mat(h[0].weight), _f32(h[0].bias)] + _bn(h[1]) + [self._mat(h[3].weight), _f32(h[3].bias)]
+            if ops.mlp2_fusable(h[0].in_features, h[0].out_features, h[3].out_features, self.dtype):
+                w2 = ops.mlp2_weight2(h[3].weight, self.dtype)   # hidden layer stays in registers: ptv3_mlp2
+            else:
+                w2 = self._mat(h[3].weight)
+            t += [self._mat(h[0].weight), _f32(h[0].bias)] + _bn(h[1]) + [w2, _f32(h[3].bias)]
         return t
 
 

@@ -36,7 +36,10 @@ SIGNATURES = {
     "ptv3_block_fusable": (c_int, [c_int, c_int, c_int, c_int64]),
     "ptv3_block_head": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     "ptv3_block_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_int, P]),
+    "ptv3_mlp2_fusable": (c_int, [c_int, c_int, c_int, c_int]),
+    "ptv3_mlp2": (c_int, [P, P, P, P, P, c_int, P, P, P, c_int, c_int64, c_int, c_int, c_int, c_int, P]),
     "ptv3_layernorm": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
+    "ptv3_layernorm_slabs": (c_int, [P, c_int, P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     "ptv3_affine_act": (c_int, [P, P, P, c_int, P, c_int64, c_int, c_int, P]),
     "ptv3_cast": (c_int, [P, c_int, P, c_int, c_int64, P]),
     "ptv3_pool_workspace_bytes": (c_size_t, [c_int64]),

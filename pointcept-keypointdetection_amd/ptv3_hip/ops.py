@@ -260,6 +260,36 @@ def block_tail(attn, f1, wproj, bproj, g2, b2, w1, bias1, w2, bias2, eps):
     return out
 
 
+def mlp2_fusable(cin, hidden, cout, dtype):
+    return bool(lib.ptv3_mlp2_fusable(int(cin), int(hidden), int(cout), _DT[dtype]))
+
+
+def mlp2_weight2(w2, dtype):
+    """(cout, hidden) parameter -> the (ceil16(cout), hidden) chain-permuted matrix ptv3_mlp2 reads."""
+    w = w2.detach().to(dtype)
+    pad = (-w.shape[0]) % 16
+    if pad:
+        w = torch.nn.functional.pad(w, (0, 0, 0, pad))
+    return chain_permute(w.contiguous(), dtype)
+
+
+def mlp2(x, w1, b1, s1, t1, act, w2p, b2, cout, out_f32=True):
+    """act((x w1^T + b1) * s1 + t1) w2^T + b2 with the hidden layer in registers; w2p from mlp2_weight2."""
+    _chk(x, "x", (torch.float32, torch.bfloat16), 2)
+    _chk(w1, "w1", x.dtype, 2)
+    _chk(w2p, "w2p", x.dtype, 2)
+    for t, nm in ((b1, "b1"), (s1, "s1"), (t1, "t1"), (b2, "b2")):
+        _chk(t, nm, torch.float32, 1)
+    m, cin = x.shape
+    hidden = w1.shape[0]
+    if w1.shape[1] != cin or w2p.shape[1] != hidden or w2p.shape[0] < cout or w2p.shape[0] % 16:
+        raise RuntimeError("mlp2: shape mismatch")
+    out = torch.empty((m, cout), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
+    lib.check(lib.ptv3_mlp2(_p(x), _p(w1), _p(b1), _p(s1), _p(t1), int(act), _p(w2p), _p(b2), _p(out), int(out_f32), m,
+                            cin, hidden, int(cout), _dt(x), _stream()), "ptv3_mlp2")
+    return out
+
+
 def layernorm(x, gamma, beta, eps=1e-5, res=None, gamma2=None, beta2=None):
     """y = LN(x)*g+b (+res); with gamma2/beta2 also returns y2 = LN(y)*g2+b2."""
     _chk(x, "x", (torch.float32, torch.bfloat16), 2)
@@ -275,6 +305,22 @@ def layernorm(x, gamma, beta, eps=1e-5, res=None, gamma2=None, beta2=None):
     y2 = torch.empty_like(x) if gamma2 is not None else None
     lib.check(lib.ptv3_layernorm(_p(x), _p(gamma), _p(beta), _p(res), _p(y), _p(gamma2), _p(beta2), _p(y2), m, c,
                                  float(eps), _dt(x), _stream()), "ptv3_layernorm")
+    return (y, y2) if gamma2 is not None else y
+
+
+def layernorm_slabs(slab, splits, m, c, slab_bias, dtype, gamma, beta, eps=1e-5, res=None, gamma2=None, beta2=None):
+    """layernorm() whose input is still the split-K slabs of conv_slabs() (its workspace tensor, `splits` slabs of
+    (m, c) fp32): x = dtype(sum slabs + slab_bias)."""
+    _chk(slab, "slab", (torch.uint8, torch.float32))
+    _chk(slab_bias, "slab_bias", torch.float32, 1)
+    _chk(res, "res", dtype, 2)
+    if slab.numel() * slab.element_size() < splits * m * c * 4:
+        raise RuntimeError("layernorm_slabs: slab buffer too small")
+    y = torch.empty((m, c), dtype=dtype, device=slab.device)
+    y2 = torch.empty_like(y) if gamma2 is not None else None
+    lib.check(lib.ptv3_layernorm_slabs(_p(slab), int(splits), _p(slab_bias), _p(gamma), _p(beta), _p(res), _p(y),
+                                       _p(gamma2), _p(beta2), _p(y2), m, c, float(eps), _DT[dtype], _stream()),
+              "ptv3_layernorm_slabs")
     return (y, y2) if gamma2 is not None else y
 
 

@@ -708,3 +708,46 @@ def test_v3m2_golden_and_oracle(dev, golden_dir):
     with torch.no_grad():
         logits = seg({k: v.to(dev) for k, v in data2.items()})["seg_logits"]
     assert logits.shape == (data2["coord"].shape[0], 13) and torch.isfinite(logits).all()
+
+
+@pytest.mark.parametrize("m,cin,hidden,cout,act", [(1000, 64, 256, 24, "relu"), (777, 32, 128, 64, "gelu"),
+                                                   (15, 64, 64, 16, "none"), (4099, 32, 256, 4, "relu")])
+def test_mlp2_vs_torch(dev, m, cin, hidden, cout, act):
+    """ptv3_mlp2 (the dense keypoint head with its hidden layer in registers) against plain torch fp32."""
+    from ptv3_hip import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(m)
+    x = torch.randn(m, cin, generator=g)
+    w1, b1 = torch.randn(hidden, cin, generator=g) / cin ** 0.5, torch.randn(hidden, generator=g)
+    s1, t1 = torch.rand(hidden, generator=g) + 0.5, torch.randn(hidden, generator=g)
+    w2, b2 = torch.randn(cout, hidden, generator=g) / hidden ** 0.5, torch.randn(cout, generator=g)
+    fn = {"relu": F.relu, "gelu": F.gelu, "none": lambda t: t}[act]
+    aid = {"relu": ops.ACT_RELU, "gelu": ops.ACT_GELU, "none": ops.ACT_NONE}[act]
+    ref = F.linear(fn(F.linear(x, w1, b1) * s1 + t1), w2, b2)
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, 0.1)):
+        assert ops.mlp2_fusable(cin, hidden, cout, dtype)
+        out = ops.mlp2(d(x).to(dtype), d(w1).to(dtype), d(b1), d(s1), d(t1), aid, ops.mlp2_weight2(d(w2), dtype), d(b2), cout)
+        assert out.dtype == torch.float32 and out.shape == (m, cout)
+        assert (out.cpu() - ref).abs().max().item() < tol
+    out16 = ops.mlp2(d(x).bfloat16(), d(w1).bfloat16(), None, None, None, aid, ops.mlp2_weight2(d(w2), torch.bfloat16),
+                     None, cout, out_f32=False)
+    assert out16.dtype == torch.bfloat16
+    assert (out16.float().cpu() - F.linear(fn(F.linear(x, w1)), w2)).abs().max().item() < 0.1
+
+
+def test_layernorm_slabs(dev):
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(4)
+    m, c, splits = 300, 256, 5
+    slab = torch.randn(splits, m, c, generator=g)
+    bias, g1, b1, g2, b2 = (torch.randn(c, generator=g) for _ in range(5))
+    res = torch.randn(m, c, generator=g)
+    x = slab.sum(0) + bias
+    F = torch.nn.functional
+    y_ref = F.layer_norm(x, (c,), g1, b1, 1e-5) + res
+    y2_ref = F.layer_norm(y_ref, (c,), g2, b2, 1e-5)
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    y, y2 = ops.layernorm_slabs(d(slab), splits, m, c, d(bias), torch.float32, d(g1), d(b1), 1e-5, res=d(res),
+                                gamma2=d(g2), beta2=d(b2))
+    assert (y.cpu() - y_ref).abs().max().item() < FP32_TOL and (y2.cpu() - y2_ref).abs().max().item() < FP32_TOL
