@@ -240,7 +240,24 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int j = 0; j < NT; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // weight fragments are fetched one stage ahead of their MFMAs (the kernel is otherwise parked on s_waitcnt:
+  // 70 % of its wave-cycles in the PMC profile): fc1's for slice h0+64 while slice h0 is computed
+  FR w1f[NKC][4];
+#pragma unroll
+  for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(16 * jj + li) * C + KC * kc + E * g);
   for (int h0 = 0; h0 < a.hidden; h0 += 64) {
+    FR w2f[HKC][NT];
+#pragma unroll
+    for (int mm = 0; mm < HKC; ++mm)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+    f32x4 bias1[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) bias1[jj] = *reinterpret_cast<const f32x4*>(a.bias1 + h0 + 16 * jj + 4 * g);
     f32x4 h[RT][4];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -249,30 +266,30 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        FR wa = *reinterpret_cast<const FR*>(w1 + (int64_t)(h0 + 16 * jj + li) * C + KC * kc + E * g);
+      for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) h[t][jj] = F::mma(wa, xf[t][kc], h[t][jj]);
-      }
+        for (int t = 0; t < RT; ++t) h[t][jj] = F::mma(w1f[kc][jj], xf[t][kc], h[t][jj]);
+    const int hn = h0 + 64 < a.hidden ? h0 + 64 : h0;   // the last slice re-reads itself (result unused)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias1 + h0 + 16 * jj + 4 * g);
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(hn + 16 * jj + li) * C + KC * kc + E * g);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[t][jj][r] = round_to<T>(gelu_erf(h[t][jj][r] + b[r]));
-    }
+        for (int r = 0; r < 4; ++r) h[t][jj][r] = round_to<T>(gelu_erf(h[t][jj][r] + bias1[jj][r]));
 #pragma unroll
     for (int mm = 0; mm < HKC; ++mm) {
       FR hf[RT];
 #pragma unroll
       for (int t = 0; t < RT; ++t) hf[t] = ChainFrag<T, 4>::get(h[t], mm);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        FR wa = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) o[t][j] = F::mma(wa, hf[t], o[t][j]);
-      }
+        for (int t = 0; t < RT; ++t) o[t][j] = F::mma(w2f[mm][j], hf[t], o[t][j]);
     }
   }
   T* out = reinterpret_cast<T*>(a.out);
@@ -330,7 +347,19 @@ __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int j = 0; j < NTO; ++j) o[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  FR w1f[CI / KC][4];
+#pragma unroll
+  for (int kc = 0; kc < CI / KC; ++kc)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(16 * jj + li) * CI + KC * kc + E * g);
   for (int h0 = 0; h0 < a.hidden; h0 += 64) {
+    FR w2f[HKC][NTO];
+#pragma unroll
+    for (int mm = 0; mm < HKC; ++mm)
+#pragma unroll
+      for (int j = 0; j < NTO; ++j)
+        w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
     f32x4 h[RT][4];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -339,11 +368,15 @@ __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
 #pragma unroll
     for (int kc = 0; kc < CI / KC; ++kc)
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        FR wa = *reinterpret_cast<const FR*>(w1 + (int64_t)(h0 + 16 * jj + li) * CI + KC * kc + E * g);
+      for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) h[t][jj] = F::mma(wa, xf[t][kc], h[t][jj]);
-      }
+        for (int t = 0; t < RT; ++t) h[t][jj] = F::mma(w1f[kc][jj], xf[t][kc], h[t][jj]);
+    const int hn = h0 + 64 < a.hidden ? h0 + 64 : h0;
+#pragma unroll
+    for (int kc = 0; kc < CI / KC; ++kc)
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(hn + 16 * jj + li) * CI + KC * kc + E * g);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int ch = h0 + 16 * jj + 4 * g;
@@ -366,11 +399,9 @@ __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
 #pragma unroll
       for (int t = 0; t < RT; ++t) hf[t] = ChainFrag<T, 4>::get(h[t], mm);
 #pragma unroll
-      for (int j = 0; j < NTO; ++j) {
-        FR wa = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+      for (int j = 0; j < NTO; ++j)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) o[t][j] = F::mma(wa, hf[t], o[t][j]);
-      }
+        for (int t = 0; t < RT; ++t) o[t][j] = F::mma(w2f[mm][j], hf[t], o[t][j]);
     }
   }
 #pragma unroll

@@ -3,5 +3,6 @@
 set -e
 R=${1:-r01}; O=gpurun_out/$R; mkdir -p profiles/$R
 cp $O/bench_n1_default.json $O/bench_n1_under_rocprof.json $O/pmc_traffic.json $O/bench_n1_trace_summary.txt profiles/$R/
+for f in pmc_sq.json bench_n1_train.json knn_query.json; do [ -f $O/$f ] && cp $O/$f profiles/$R/; done
 cp "$(ls -t $O/stats/*/*_kernel_stats.csv | head -1)" profiles/$R/bench_n1_default_kernel_stats.csv
 ls -la profiles/$R

@@ -8,12 +8,24 @@ export TMPDIR=/tmp
 #       tools/collect_round.sh $R (runs in the build container).
 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log | tail -1 > $O/bench_n1_default.json
 echo "bench done: $(cut -c1-160 $O/bench_n1_default.json)"
+rm -rf $O/stats $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --cpu-sample 0 > $O/bench_stats.log 2>&1
 grep '^{"metric"' $O/bench_stats.log | tail -1 > $O/bench_n1_under_rocprof.json
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-kernel-events > $O/pmc_$c.log 2>&1
 done
-python tools/pmc_traffic.py $O/pmc_FETCH_SIZE/*/*_counter_collection.csv $O/pmc_WRITE_SIZE/*/*_counter_collection.csv 5 \
+rm -f $O/pmc_traffic.json
+python tools/pmc_traffic.py "$(ls -t $O/pmc_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls -t $O/pmc_WRITE_SIZE/*/*_counter_collection.csv | head -1)" 5 \
   $O/pmc_traffic.json '{"points": 100000, "scenes": 1, "dtype": "bf16", "kind": "surface"}'
-python tools/summarize_trace.py $O/stats/*/*_kernel_trace.csv 15 > $O/bench_n1_trace_summary.txt
+python tools/summarize_trace.py "$(ls -t $O/stats/*/*_kernel_trace.csv | head -1)" 15 > $O/bench_n1_trace_summary.txt
 head -12 $O/bench_n1_trace_summary.txt
+# issue / stall / matrix-core shares per kernel (SQ counters; separate pass, no other trace domains)
+rm -rf $O/pmc_sq
+rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU \
+  --kernel-trace --output-format csv -d $O/pmc_sq -- python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-kernel-events > $O/pmc_sq.log 2>&1
+python tools/pmc_sq.py "$(ls -t $O/pmc_sq/*/*_counter_collection.csv | head -1)" 5 $O/pmc_sq.json
+# the training step and kNN (A18)
+python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | grep '^{"metric"' > $O/bench_n1_train.json
+cut -c1-220 $O/bench_n1_train.json
+python tools/bench_pointops.py > $O/knn_query.json 2>/dev/null; python tools/bench_pointops.py 100000 100000 16 >> $O/knn_query.json 2>/dev/null
+cat $O/knn_query.json | cut -c1-160
