@@ -63,6 +63,21 @@ def pmc_traffic(args, kernel_family):
                                        "launches_per_step": k["launches_per_step"]}
 
 
+def pmc_sq():
+    """Matrix-core utilisation and stall shares of the two main kernels from the committed SQ counter pass
+    (tools/measure_round.sh -> profiles/<round>/pmc_sq.json; default workload only)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_sq.json")))
+    if not files:
+        return None
+    data = json.load(open(files[-1])).get("kernels", {})
+    keep = ("mfma_util", "share_issuing", "share_issue_stall", "share_parked")
+    out = {k: {f: v[f] for f in keep if f in v} for k, v in data.items()
+           if k in ("window_attn_full_kernel", "gemm_kernel<bf16,64ch>")}
+    return {"source": os.path.relpath(files[-1], ROOT),
+            "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)", **out} if out else None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -288,6 +303,8 @@ def main():
 
     if roofline is not None and rank == 0:
         roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(args, roofline["kernel"])
+        if (args.points, args.scenes, args.dtype, args.kind) == (100000, 1, "bf16", "surface"):
+            roofline["pmc_sq"] = pmc_sq()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         line = {
