@@ -247,9 +247,21 @@ typedef struct {
   int32_t inputs_resident;                      /* 1: grid_coord / batch / offset were complete in memory before
                                                    this call (not produced on `stream` just now): the geometry
                                                    pipeline may then overlap the previous call's feature tail */
+  int32_t overlap_calls;                        /* 1 (needs inputs_resident, parameters unchanged since an earlier
+                                                   synchronised call): the feature pipeline runs on one of two
+                                                   executor-owned streams instead of `stream`, so the small, latency-
+                                                   bound deep levels of call i execute under the chip-filling level-0
+                                                   kernels of call i+1.  `stream` only receives a wait on this call's
+                                                   completion.  Contract: out_feat / out_head must not be buffers whose
+                                                   last readers were enqueued on `stream` after the PREVIOUS call was
+                                                   issued (use a ring of >= 3 output buffers, consume call i's outputs
+                                                   before issuing call i+2). */
+  const void* raw_feat;                         /* overlap mode, optional: (n, raw_feat_channels) features still in   */
+  int32_t raw_feat_channels;                    /* their original dtype / width; the executor pads them to            */
+  int32_t raw_feat_dtype;                       /* desc->in_channels and casts to desc->dtype on its own stream       */
 } ptv3_forward_io;
 
-size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b);
+size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b);  /* sized for overlap_calls too */
 int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
                  const ptv3_forward_io* io, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -99,6 +99,7 @@ struct Level {
 };
 
 static hipStream_t g_geo_stream = nullptr;
+static hipStream_t g_feat_stream[2] = {nullptr, nullptr};  // overlap_calls: feature pipelines of consecutive calls
 static std::vector<hipEvent_t> g_events;
 static unsigned g_call = 0;  // calls alternate between the two geometry arenas (see ptv3_forward)
 static double g_sync_us = 0.0;  // host time blocked in geometry-stream read-backs (PTV3_ENGINE_TIMING=1)
@@ -119,6 +120,26 @@ static hipEvent_t event_at(size_t i) {
     g_events.push_back(e);
   }
   return g_events[i];
+}
+
+// (n, cin) rows in their original dtype -> (n, cpad) rows of the compute dtype, zero-padded
+template <typename S, typename D>
+__global__ void pad_cast_kernel(const S* __restrict__ x, int cin, D* __restrict__ y, int cpad, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * cpad) return;
+  const int c = (int)(i % cpad);
+  y[i] = from_f32<D>(c < cin ? to_f32<S>(x[(i / cpad) * cin + c]) : 0.f);
+}
+static void pad_cast(const void* x, int sdt, int cin, void* y, int ddt, int cpad, int64_t n, hipStream_t s) {
+  dim3 grid((unsigned)cdiv(n * cpad, 256)), block(256);
+  if (sdt == PTV3_F32 && ddt == PTV3_F32)
+    hipLaunchKernelGGL((pad_cast_kernel<float, float>), grid, block, 0, s, (const float*)x, cin, (float*)y, cpad, n);
+  else if (sdt == PTV3_F32)
+    hipLaunchKernelGGL((pad_cast_kernel<float, __bf16>), grid, block, 0, s, (const float*)x, cin, (__bf16*)y, cpad, n);
+  else if (ddt == PTV3_F32)
+    hipLaunchKernelGGL((pad_cast_kernel<__bf16, float>), grid, block, 0, s, (const __bf16*)x, cin, (float*)y, cpad, n);
+  else
+    hipLaunchKernelGGL((pad_cast_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)x, cin, (__bf16*)y, cpad, n);
 }
 
 struct Run {
@@ -344,7 +365,15 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
     wait_level(L0);
     const int C0 = d->enc_channels[0];
     L0.feat = F.alloc((size_t)L0.n * C0 * es); L0.channels = C0;
-    R.gemm(io->feat, stem_w, L0.feat, L0.n, d->in_channels, C0, 125, L0.nbr5, L0.row_order, nullptr, stem_s, stem_t,
+    const void* feat_in = io->feat;
+    if (io->raw_feat) {
+      // overlap mode: pad + cast the caller's features here, on the executor's stream (no producer on `stream`)
+      void* padded = F.alloc((size_t)L0.n * d->in_channels * es);
+      if (!dry && R.ok())
+        pad_cast(io->raw_feat, io->raw_feat_dtype, io->raw_feat_channels, padded, d->dtype, d->in_channels, L0.n, sf);
+      feat_in = padded;
+    }
+    R.gemm(feat_in, stem_w, L0.feat, L0.n, d->in_channels, C0, 125, L0.nbr5, L0.row_order, nullptr, stem_s, stem_t,
            PTV3_ACT_GELU, nullptr, nullptr, nullptr);
     L0.conv_feat = L0.feat;
   }
@@ -506,7 +535,7 @@ extern "C" size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int6
   if (check_desc(desc)) return 0;
   size_t g, f;
   plan_bytes(desc, n, b, &g, &f, nullptr);
-  return 2 * g + f + 512;  // two geometry arenas (consecutive calls alternate), one feature arena
+  return 2 * g + 2 * f + 512;  // two geometry arenas (consecutive calls alternate), two feature arenas (overlap_calls)
 }
 
 extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
@@ -520,8 +549,14 @@ extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* para
   plan_bytes(desc, io->n, io->b, &g, &f, &count);
   PTV3_REQUIRE(count == num_params, "forward: %d parameter pointers given, the model description needs %d",
                num_params, count);
-  PTV3_REQUIRE(workspace_bytes >= 2 * g + f + 256, "forward: workspace %zu bytes < %zu (ptv3_forward_workspace_bytes)",
-               workspace_bytes, 2 * g + f + 256);
+  const bool overlap = io->overlap_calls != 0;
+  PTV3_REQUIRE(!overlap || io->inputs_resident, "forward: overlap_calls needs inputs_resident");
+  PTV3_REQUIRE(io->raw_feat == nullptr || (io->raw_feat_channels >= 1 && io->raw_feat_channels <= desc->in_channels &&
+                                           (io->raw_feat_dtype == PTV3_F32 || io->raw_feat_dtype == PTV3_BF16)),
+               "forward: bad raw_feat description");
+  const size_t need = 2 * g + (overlap ? 2 : 1) * f + 256;
+  PTV3_REQUIRE(workspace_bytes >= need, "forward: workspace %zu bytes < %zu (ptv3_forward_workspace_bytes)",
+               workspace_bytes, need);
   char* base = (char*)workspace;
   size_t goff = (256 - ((uintptr_t)base & 255)) & 255;
   ++g_call;
@@ -529,9 +564,27 @@ extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* para
   const double t_begin = timing ? now_us() : 0.0;
   g_sync_us = 0.0;
   event_at(21);  // make sure the two arena events exist (an unrecorded event never blocks a wait)
-  Arena G{base + goff + (g_call & 1) * g, g, 0, 0, false, false};
-  Arena F{base + goff + 2 * g, f, 0, 0, false, false};
-  int rc = run_forward(desc, params, io, G, F, (hipStream_t)stream, false, nullptr);
+  const unsigned par = g_call & 1;
+  hipStream_t caller = (hipStream_t)stream, sf = caller;
+  if (overlap) {
+    if (!g_feat_stream[par] && hipStreamCreateWithFlags(&g_feat_stream[par], hipStreamNonBlocking) != hipSuccess) {
+      set_error("forward: cannot create the feature stream");
+      return PTV3_ERR_LAUNCH;
+    }
+    sf = g_feat_stream[par];
+    event_at(33);
+    // the output buffers this call overwrites were last read by work the caller enqueued before the PREVIOUS call
+    // started (contract in the header): wait for that marker, never for the previous call itself
+    (void)hipStreamWaitEvent(sf, event_at(30 + (par ^ 1)), 0);
+    (void)hipEventRecord(event_at(30 + par), caller);
+  }
+  Arena G{base + goff + par * g, g, 0, 0, false, false};
+  Arena F{base + goff + 2 * g + (overlap ? par * f : 0), f, 0, 0, false, false};
+  int rc = run_forward(desc, params, io, G, F, sf, false, nullptr);
+  if (overlap) {
+    (void)hipEventRecord(event_at(32 + par), sf);
+    (void)hipStreamWaitEvent(caller, event_at(32 + par), 0);  // the caller's later work sees this call's outputs
+  }
   if (timing)
     fprintf(stderr, "[ptv3_forward] host %.0f us total, %.0f us blocked in read-backs\n", now_us() - t_begin, g_sync_us);
   return rc;

@@ -535,6 +535,11 @@ class PointTransformerV3(PointModule):
         # produced on the current stream just now); consecutive forwards then pipeline (geometry of call i+1
         # under the feature tail of call i).  Default False = fully stream-ordered.
         self.inputs_resident = False
+        # True (with inputs_resident, native executor only): throughput mode - the whole feature pipeline runs on
+        # executor-owned streams so consecutive forwards overlap (deep, latency-bound levels of call i under the
+        # level-0 kernels of call i+1).  Outputs then live in a ring of three executor-owned buffers: consume the
+        # result of call i before issuing call i+2 (ptv3_forward_io.overlap_calls in include/ptv3_hip.h).
+        self.overlap_calls = False
 
         assert self.num_stages == len(stride) + 1
         assert self.num_stages == len(enc_depths)
@@ -624,7 +629,8 @@ class PointTransformerV3(PointModule):
             feat = point.feat
             if feat.dtype not in (torch.float32, torch.bfloat16):
                 feat = feat.float()
-            point.feat = ops.cast(feat.contiguous(), dtype)
+            overlap = use_engine and self.overlap_calls and self.inputs_resident
+            point.feat = feat.contiguous() if overlap else ops.cast(feat.contiguous(), dtype)
             if use_engine:
                 point._ensure_grid_coord()
                 point, head_out = _engine.forward(self, point, dtype, _head)

@@ -24,7 +24,8 @@ class ForwardIO(ctypes.Structure):
                 ("depth", c_int32), ("order_ids_host", POINTER(c_int32)), ("pool_perm_host", POINTER(c_int32)),
                 ("code", c_void_p), ("order", c_void_p), ("inverse", c_void_p), ("out_feat", c_void_p),
                 ("out_head", c_void_p), ("stage_points_host", POINTER(c_int64)), ("depth_out", POINTER(c_int32)),
-                ("batch_out", c_void_p), ("inputs_resident", c_int32)]
+                ("batch_out", c_void_p), ("inputs_resident", c_int32), ("overlap_calls", c_int32),
+                ("raw_feat", c_void_p), ("raw_feat_channels", c_int32), ("raw_feat_dtype", c_int32)]
 
 
 def declare(dll):
@@ -55,6 +56,7 @@ class Packed:
             self.sources += list(head.parameters()) + list(head.buffers())
         self.versions = None
         self.tensors = None
+        self.repacked = False
 
     def fresh(self):
         v = [t._version for t in self.sources]
@@ -63,6 +65,7 @@ class Packed:
                 self.tensors = self._pack()
             self.table = (c_void_p * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
             self.versions = v
+            self.repacked = True
         return self
 
     def _mat(self, w, cin_pad=None):
@@ -217,8 +220,17 @@ def forward(backbone, point, dtype, head=None):
 
     feat = point.feat
     n = feat.shape[0]
-    if feat.shape[1] != pk.cin_pad:
+    # overlap mode (backbone.overlap_calls + inputs_resident): nothing may be produced on the caller's stream for
+    # this call, so the pad / cast of the features moves into the executor and the outputs come from a ring
+    overlap = bool(getattr(backbone, "overlap_calls", False)) and bool(getattr(backbone, "inputs_resident", False))
+    raw = None
+    if overlap:
+        raw = feat
+        if pk.repacked:                      # parameter tables were (re)built on this stream: settle them once
+            torch.cuda.current_stream().synchronize()
+    elif feat.shape[1] != pk.cin_pad:
         feat = torch.nn.functional.pad(feat, (0, pk.cin_pad - feat.shape[1])).contiguous()
+    pk.repacked = False
     gc = point.grid_coord
     if gc.dtype not in (torch.int32, torch.int64):
         gc = gc.long()
@@ -231,8 +243,21 @@ def forward(backbone, point, dtype, head=None):
     code = torch.empty((k, n), dtype=torch.int64, device=dev)
     order = torch.empty_like(code)
     inverse = torch.empty_like(code)
-    out_feat = torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev)
-    out_head = torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None
+    if overlap:
+        ring = backbone.__dict__.setdefault("_engine_out_ring", {})
+        rkey = (n, desc.dec_channels[0], dtype, desc.head_out if head is not None else 0, dev)
+        slot = ring.get(rkey)
+        if slot is None:   # three generations: call i's outputs stay valid until call i+3 is issued
+            slot = ring[rkey] = {"i": 0, "bufs": [
+                (torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev),
+                 torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None)
+                for _ in range(3)]}
+            torch.cuda.current_stream().synchronize()
+        out_feat, out_head = slot["bufs"][slot["i"] % 3]
+        slot["i"] += 1
+    else:
+        out_feat = torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev)
+        out_head = torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None
     ws_bytes = dll.ptv3_forward_workspace_bytes(ctypes.byref(desc), n, nb)
     arena = backbone.__dict__.get("_engine_arena")
     if arena is None or arena.numel() < ws_bytes or arena.device != dev:
@@ -242,6 +267,12 @@ def forward(backbone, point, dtype, head=None):
     io = ForwardIO()
     io.grid_coord, io.coord_is_i64 = gc.data_ptr(), int(gc.dtype == torch.int64)
     io.feat, io.offset = feat.data_ptr(), offset.data_ptr()
+    io.overlap_calls = int(overlap)
+    if raw is not None:
+        io.raw_feat, io.raw_feat_channels = raw.data_ptr(), raw.shape[1]
+        io.raw_feat_dtype = PTV3_F32 if raw.dtype == torch.float32 else PTV3_BF16
+    else:
+        io.raw_feat = None
     if derive_batch:   # the executor fills point.batch itself (geometry stream)
         io.batch, io.batch_out = None, batch.data_ptr()
         del point["_batch_pending"]

@@ -470,6 +470,30 @@ def test_pipelined_calls_match_serial(dev):
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
         assert torch.equal(o, serial[i % len(scenes)]), i
+    # throughput mode: whole feature pipelines of consecutive calls overlap on executor-owned streams
+    # (ptv3_forward_io.overlap_calls; outputs in a ring of three, consumed here by the model's own clone)
+    model.backbone.overlap_calls = True
+    outs = []
+    for rep in range(4):
+        for sc in scenes:
+            torch.manual_seed(9)
+            with torch.no_grad():
+                outs.append(model(sc)["pred"])
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, serial[i % len(scenes)]), i
+    # fp32 features in, bf16 compute: the pad + cast moves into the executor in this mode
+    model.backbone.overlap_calls = False
+    model.backbone.compute_dtype = torch.bfloat16
+    torch.manual_seed(9)
+    with torch.no_grad():
+        ref16 = model(scenes[0])["pred"].clone()
+    model.backbone.overlap_calls = True
+    for _ in range(3):
+        torch.manual_seed(9)
+        with torch.no_grad():
+            got16 = model(scenes[0])["pred"]
+        assert torch.equal(got16, ref16)
 
 
 @pytest.mark.parametrize("sizes,kind,extent", [([12000, 9000], "surface", 128), ([15000], "lidar", 1024)])
