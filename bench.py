@@ -274,6 +274,9 @@ def main():
     # matrix-core launch.  Kept out of the timed region above because the ~340 event records per step are
     # queue markers that cost ~1.5 ms per step (measured: 5.0 ms vs 3.4 ms) - they would falsify `value`.
     if not args.no_kernel_events:
+        # one forward in flight here: with two overlapped forwards an event bracket would time the kernel while it
+        # shares the chip with the other forward's kernels; the roofline entry describes the kernel alone
+        model.backbone.overlap_calls = False
         ops.profile_enable(True)
         for _ in range(args.steps):
             step()
@@ -291,7 +294,8 @@ def main():
         # which roof binds this family: algorithmic intensity against the machine balance of the dtype
         intensity = d["flops"] / max(d["bytes"], 1.0)
         hbm_bound = intensity * PEAK_HBM * 1e9 < PEAK[args.dtype] * 1e12
-        roofline = {"kernel": dom, "measured": f"HIP events on the launch stream, {args.steps} extra steps after the timed region",
+        roofline = {"kernel": dom, "measured": f"HIP events on the launch stream, {args.steps} extra steps after the timed region, one forward "
+                                "in flight",
                     "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": round(gbs if hbm_bound else tf, 3),
                     "peak": PEAK_HBM if hbm_bound else PEAK[args.dtype],
