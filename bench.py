@@ -220,10 +220,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; PTV3_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on ONE GPU (RCCL
+    # needs a device per rank) - used only to test this script, never for reported numbers
+    backend = os.environ.get("PTV3_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import ptv3_scenes as S
@@ -232,7 +239,7 @@ def main():
 
     cpu, parity = None, None
     if args.mode == "train":
-        return train_bench(args, model, device, world, rank, local_rank)
+        return train_bench(args, model, device, world, rank, dev_index)
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         cpu, parity = cpu_baseline(sd, cfg, model, device, args.cpu_sample)
 
