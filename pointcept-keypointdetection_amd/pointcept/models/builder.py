@@ -1,12 +1,12 @@
-"""MODELS / MODULES registries and build_model (reference: pointcept/models/builder.py:12-17)."""
-import copy
+"""Model registries of the package (interface of the reference's pointcept/models/builder.py:12-17):
+`MODELS` holds backbones and wrappers, `MODULES` reusable parts; `build_model(cfg)` instantiates
+`cfg["type"]` from `MODELS` with the remaining keys and never mutates the caller's config."""
+from copy import deepcopy
 
 from pointcept.utils.registry import Registry
 
-MODELS = Registry("models")
-MODULES = Registry("modules")
+MODELS, MODULES = Registry("models"), Registry("modules")
 
 
 def build_model(cfg):
-    """Deep-copies cfg, pops "type", instantiates the registered class with the remaining keys."""
-    return MODELS.build(copy.deepcopy(cfg))
+    return MODELS.build(deepcopy(cfg))

@@ -1,22 +1,25 @@
-"""Criteria builder (reference: pointcept/models/losses/builder.py). Losses are plain torch, out of the
-MI355X hot path; kept so DefaultSegmentorV2 configs build unchanged."""
+"""Loss registry + the `Criteria` aggregate the segmentor wrappers call (interface of the reference's
+pointcept/models/losses/builder.py).  Losses are plain torch and sit outside the MI355X hot path
+(SURVEY.md section 2a row 9); the registry exists so DefaultSegmentorV2 configs build unchanged."""
+from functools import reduce
+
 from pointcept.utils.registry import Registry
 
 LOSSES = Registry("losses")
 
 
-class Criteria(object):
+class Criteria:
+    """Sum of the configured losses; with no loss configured the prediction passes through (the model computes
+    its own loss, as OffsetKeypointPTv3 does)."""
+
     def __init__(self, cfg=None):
-        self.cfg = cfg if cfg is not None else []
-        self.criteria = [LOSSES.build(cfg=loss_cfg) for loss_cfg in self.cfg]
+        self.cfg = list(cfg) if cfg else []
+        self.criteria = [LOSSES.build(cfg=c) for c in self.cfg]
 
     def __call__(self, pred, target):
-        if len(self.criteria) == 0:
-            return pred  # loss computed inside the model
-        loss = 0
-        for c in self.criteria:
-            loss += c(pred, target)
-        return loss
+        if not self.criteria:
+            return pred
+        return reduce(lambda acc, fn: acc + fn(pred, target), self.criteria, 0)
 
 
 def build_criteria(cfg):

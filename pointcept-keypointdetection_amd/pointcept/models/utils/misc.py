@@ -1,36 +1,41 @@
-"""offset <-> batch helpers (reference: pointcept/models/utils/misc.py:13-34). Index plumbing on torch."""
+"""offset <-> batch index helpers with the names of the reference's pointcept/models/utils/misc.py:13-34
+(pure index plumbing, evaluated by torch).  Two departures, both to keep the launch stream free of hidden
+host synchronisation: the leading zero is created on the device (`new_zeros`, not a host list), and
+`offset2batch` takes the known number of points so that `repeat_interleave` need not read its size back."""
 import torch
 
 
-@torch.no_grad()
+def _no_grad(fn):
+    return torch.no_grad()(fn)
+
+
+@_no_grad
 def offset2bincount(offset):
-    # new_zeros instead of the reference's torch.tensor([0], device=...): a host list -> device copy is a
-    # blocking transfer on the current stream, i.e. a hidden pipeline drain in front of every forward
+    """cumulative scene ends -> points per scene"""
     return torch.diff(offset, prepend=offset.new_zeros(1))
 
 
-@torch.no_grad()
+@_no_grad
 def bincount2offset(bincount):
-    return torch.cumsum(bincount, dim=0)
+    return bincount.cumsum(0)
 
 
-@torch.no_grad()
+@_no_grad
 def offset2batch(offset, num_points=None):
-    """num_points (= offset[-1], known from any per-point tensor) avoids the device->host read that
-    repeat_interleave otherwise needs to size its output."""
-    bincount = offset2bincount(offset)
-    ids = torch.arange(len(bincount), device=offset.device, dtype=torch.long)
-    if num_points is not None:
-        return ids.repeat_interleave(bincount, output_size=int(num_points))
-    return ids.repeat_interleave(bincount)
+    counts = offset2bincount(offset)
+    scene = torch.arange(counts.numel(), device=offset.device, dtype=torch.long)
+    extra = {} if num_points is None else {"output_size": int(num_points)}
+    return scene.repeat_interleave(counts, **extra)
 
 
-@torch.no_grad()
+@_no_grad
 def batch2offset(batch):
-    return torch.cumsum(batch.bincount(), dim=0).long()
+    return batch.bincount().cumsum(0).long()
 
 
 def off_diagonal(x):
-    n, m = x.shape
-    assert n == m
-    return x.flatten()[:-1].view(n - 1, n + 1)[:, 1:].flatten()
+    """all entries of a square matrix except its diagonal, flattened (row-major)"""
+    rows, cols = x.shape
+    if rows != cols:
+        raise AssertionError("off_diagonal expects a square matrix")
+    return x.flatten()[:-1].view(rows - 1, rows + 1)[:, 1:].flatten()
