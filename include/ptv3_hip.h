@@ -88,6 +88,18 @@ int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, const int32_
                          void* out, int64_t n, int64_t n_pad, int c, int heads, int patch, float scale,
                          const float* rpe_bias, int dtype, void* stream);
 
+/* Same attention with the relative-position bias of RPE (point_transformer_v3m1_base.py:29-48 applied to
+ * get_rel_pos :104-112) evaluated INSIDE the kernel: bias(q, k, h) = sum over the 3 axes of
+ * rpe_table[axis * (2*pos_bnd+1) + clamp(grid[q][axis] - grid[k][axis], -pos_bnd, pos_bnd) + pos_bnd][h],
+ * from the window's voxel coordinates and the head's table column held in LDS - the (windows, H, K, K) bias
+ * tensor of the rpe_bias argument above (3.3 GB per call at 100k points, K = 1024) is never built.
+ * grid_coord (n, 3) int32 in point order; rpe_table (3*(2*pos_bnd+1), heads) fp32.  PTV3_ERR_UNSUPPORTED when the
+ * window does not fit the resident-window kernel (then build the dense bias and use ptv3_window_attn_fwd). */
+int ptv3_window_attn_rpe_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse, void* out,
+                             int64_t n, int64_t n_pad, int c, int heads, int patch, float scale,
+                             const int32_t* grid_coord, const float* rpe_table, int pos_bnd, int dtype,
+                             void* stream);
+
 /* ---- sparse submanifold convolution + dense linear (one implicit-GEMM kernel) ---------------
  * Hash of the active sites: replaces spconv's indice-pair generation behind
  * spconv.SparseConvTensor / SubMConv3d(indice_key=...) (models/utils/structure.py:111-146,

@@ -254,11 +254,18 @@ template <> struct RowSum<float> {
   static __device__ __forceinline__ f32x4 ones() { return f32x4{1.f, 1.f, 1.f, 1.f}; }
 };
 
-template <typename T, int ND, bool RPE>
+// RPE: 0 none; 1 dense bias tensor (windows, H, K, K) streamed from memory; 2 the reference's table lookup
+// (RPE.forward, point_transformer_v3m1_base.py:29-48 on get_rel_pos :104-112) evaluated in the kernel:
+// bias(q, k) = sum_axis table[axis*rpe_num + clamp(grid[q][axis] - grid[k][axis], -bnd, bnd) + bnd][head]
+// from the window's voxel coordinates and the head's table column, both resident in LDS.
+struct RpeTable { const int32_t* grid; const float* table; int pos_bnd; };
+
+template <typename T, int ND, int RPE>
 __global__ void __launch_bounds__(512)
 window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
                         const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
-                        int Kpad, int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe) {
+                        int Kpad, int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe,
+                        RpeTable rt) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
@@ -272,6 +279,9 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   T* sK = reinterpret_cast<T*>(smem);                         // [Kpad][KS]
   T* sV = sK + (size_t)Kpad * KS;                             // [D][VS]
   int32_t* sOrd = reinterpret_cast<int32_t*>(sV + (size_t)D * VS);  // [Kpad]
+  int32_t* sGC = sOrd + Kpad;                                       // RPE == 2: [Kpad][3] voxel coordinates
+  const int rpe_num = 2 * rt.pos_bnd + 1;
+  float* sTab = reinterpret_cast<float*>(sGC + 3 * Kpad);           // RPE == 2: [3*rpe_num] this head's column
 
   const unsigned nwg = (unsigned)nwin * H * qsplit;
   const unsigned logical = xcd_remap(blockIdx.x, nwg);
@@ -287,6 +297,14 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
 
   for (int i = tid; i < Kpad; i += nthreads) sOrd[i] = i < K ? win_order[wbase + i] : -1;
   __syncthreads();
+  if constexpr (RPE == 2) {
+    for (int i = tid; i < Kpad; i += nthreads) {
+      const int row = sOrd[i];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) sGC[3 * i + d] = row >= 0 ? rt.grid[(int64_t)row * 3 + d] : 0;
+    }
+    for (int j = tid; j < 3 * rpe_num; j += nthreads) sTab[j] = rt.table[(int64_t)j * H + h] * 1.44269504088896340736f;
+  }
 
   // ---- stage the whole window: K row-major, V transposed
   constexpr int CH = D / 4;
@@ -323,6 +341,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   // ---- Q fragments of this wave (global loads overlap the staging above)
   V4 qf[QT][ND];
   int qidx[QT];
+  int qg[QT][3];
   bool any_q = false;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -330,6 +349,10 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
     const bool qv = qidx[t] < K;
     any_q |= qv;
     const int row = qv ? sOrd[qidx[t]] : 0;
+    if constexpr (RPE == 2) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) qg[t][d] = qv ? rt.grid[(int64_t)row * 3 + d] : 0;
+    }
 #pragma unroll
     for (int c = 0; c < ND; ++c) {
       V4 raw = zero4<T>();
@@ -375,7 +398,22 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
         for (int c = 0; c < ND; ++c) acc = mma16<T>(kf[kt][c], qf[t][c], acc);
         s[kt] = acc;
       }
-      if constexpr (RPE) {
+      if constexpr (RPE == 2) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int* kg = sGC + 3 * (key0 + 16 * kt + 4 * g + r);
+            float bias = 0.f;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+              const int rel = min(max(qg[t][d] - kg[d], -rt.pos_bnd), rt.pos_bnd) + rt.pos_bnd;
+              bias += sTab[d * rpe_num + rel];
+            }
+            s[kt][r] += bias;
+          }
+      }
+      if constexpr (RPE == 1) {
         if (qidx[t] < K) {
           const float* rb = rpe + (((int64_t)w * H + h) * K + qidx[t]) * K;
 #pragma unroll
@@ -465,11 +503,17 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
 
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
-                              int K, int nwin, float scale, const float* rpe, hipStream_t s) {
+                              int K, int nwin, float scale, const float* rpe, hipStream_t s,
+                              RpeTable rt = RpeTable{nullptr, nullptr, 0}) {
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
   const int Kpad = (K + WA_KT - 1) / WA_KT * WA_KT;
-  const size_t lds_full = ((size_t)Kpad * (D + 4) + (size_t)D * (Kpad + WaFull<T>::VPAD)) * sizeof(T) + (size_t)Kpad * 4;
+  size_t lds_full = ((size_t)Kpad * (D + 4) + (size_t)D * (Kpad + WaFull<T>::VPAD)) * sizeof(T) + (size_t)Kpad * 4;
+  if (rt.table) lds_full += (size_t)Kpad * 12 + (size_t)3 * (2 * rt.pos_bnd + 1) * 4;
+  if (rt.table && lds_full > 160 * 1024) {
+    set_error("window_attn_rpe: window of %d keys does not fit the resident-window kernel", K);
+    return PTV3_ERR_UNSUPPORTED;
+  }
   static bool attr_set = false;
   if (lds_full <= 160 * 1024) {
     // queries per workgroup: 8 waves (512 queries at head_dim 16) when there are plenty of windows, fewer
@@ -485,21 +529,27 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
     const int QB = waves * QT * 16;
     const int qsplit = (K + QB - 1) / QB;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, false>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, 0>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, true>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, 1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, 2>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
     const unsigned nwg = (unsigned)nwin * H * qsplit;
-    if (rpe)
-      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, true>), dim3(nwg), dim3(waves * 64), lds_full, s,
+    if (rt.table)
+      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, 2>), dim3(nwg), dim3(waves * 64), lds_full, s,
                          (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
-                         scale * 1.44269504088896340736f, rpe);
+                         scale * 1.44269504088896340736f, rpe, rt);
+    else if (rpe)
+      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, 1>), dim3(nwg), dim3(waves * 64), lds_full, s,
+                         (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
+                         scale * 1.44269504088896340736f, rpe, rt);
     else
-      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, false>), dim3(nwg), dim3(waves * 64), lds_full, s,
+      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, 0>), dim3(nwg), dim3(waves * 64), lds_full, s,
                          (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
-                         scale * 1.44269504088896340736f, rpe);
+                         scale * 1.44269504088896340736f, rpe, rt);
     PTV3_LAUNCH_CHECK();
     return PTV3_OK;
   }
@@ -547,6 +597,42 @@ extern "C" int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, c
   }
   if (dtype == PTV3_F32) { WA_CASE(float) } else { WA_CASE(__bf16) }
 #undef WA_CASE
+  prof_end(prof, s);
+  return rc;
+}
+
+extern "C" int ptv3_window_attn_rpe_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                        void* out, int64_t n, int64_t n_pad, int c, int heads, int patch, float scale,
+                                        const int32_t* grid_coord, const float* rpe_table, int pos_bnd, int dtype,
+                                        void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_rpe: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_rpe: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(n_pad % patch == 0, "window_attn_rpe: n_pad=%lld is not a multiple of patch=%d", (long long)n_pad, patch);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_rpe: bad dtype %d", dtype);
+  PTV3_REQUIRE(grid_coord && rpe_table && pos_bnd >= 0 && pos_bnd <= 4096, "window_attn_rpe: grid_coord, rpe_table and 0 <= pos_bnd <= 4096 are required");
+  const int d = c / heads;
+  if (n == 0) return PTV3_OK;
+  if (d != 16 && d != 32 && d != 64) {
+    set_error("window_attn_rpe: head_dim %d unsupported (16, 32, 64)", d);
+    return PTV3_ERR_UNSUPPORTED;
+  }
+  const int nwin = (int)(n_pad / patch);
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_WINDOW_ATTN, 4.0 * n_pad * patch * c,
+                              (double)n_pad * 3 * c * esz + (double)n * c * esz + 4.0 * (n_pad + n) + 12.0 * n_pad,
+                              nullptr, 0, 0.0);
+  const RpeTable rt{grid_coord, rpe_table, pos_bnd};
+  int rc = PTV3_ERR_UNSUPPORTED;
+#define WAR_CASE(T)                                                                                                    \
+  switch (d) {                                                                                                         \
+    case 16: rc = launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, nullptr, s, rt); break; \
+    case 32: rc = launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, nullptr, s, rt); break; \
+    case 64: rc = launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, nullptr, s, rt); break; \
+    default: break;                                                                                                    \
+  }
+  if (dtype == PTV3_F32) { WAR_CASE(float) } else { WAR_CASE(__bf16) }
+#undef WAR_CASE
   prof_end(prof, s);
   return rc;
 }

@@ -40,8 +40,8 @@ class RPE(nn.Module):
         nn.init.trunc_normal_(self.rpe_table, std=0.02)
 
     def forward(self, coord):
-        # index plumbing (clamp / offset / gather of a (3*rpe_num, H) table); the bias is consumed by the
-        # HIP attention kernel.  TODO(next): fold the table lookup into the kernel.
+        # dense fallback only (windows too large for the resident-window kernel): index plumbing that materialises
+        # the (windows, H, K, K) bias; the normal path is ops.window_attention_rpe (table lookup inside the kernel)
         idx = (coord.clamp(-self.pos_bnd, self.pos_bnd) + self.pos_bnd
                + torch.arange(3, device=coord.device) * self.rpe_num)
         out = self.rpe_table.float().index_select(0, idx.reshape(-1))
@@ -126,6 +126,13 @@ class SerializedAttention(PointModule):
         bias = None
         if self.enable_rpe:
             _no_training(self)  # the backward kernel has no bias-gradient path yet
+            gkey = "_grid_coord_i32"
+            if gkey not in point.keys():
+                point[gkey] = point.grid_coord.int().contiguous()
+            out = ops.window_attention_rpe(qkv, wo, wi, self.num_heads, K, self.scale, point[gkey],
+                                           self.rpe.rpe_table.detach().float().contiguous(), self.rpe.pos_bnd)
+            if out is not None:
+                return out
             bias = self.rpe(self.get_rel_pos(point, wo.long()))
         if self.training:
             return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale)

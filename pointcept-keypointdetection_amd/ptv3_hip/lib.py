@@ -26,6 +26,8 @@ SIGNATURES = {
     "ptv3_window_maps": (c_int, [P, P, P, P, c_int64, c_int64, P, P, P]),
     "ptv3_window_plan": (c_int, [P, P, P, c_int, c_int, c_int64, c_int64, c_int, P, P, P]),
     "ptv3_window_attn_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, P, c_int, P]),
+    "ptv3_window_attn_rpe_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, P, P, c_int,
+                                         c_int, P]),
     "ptv3_subm_table_slots": (c_int64, [c_int64]),
     "ptv3_subm_build_table": (c_int, [P, c_int64, P, c_int64, P]),
     "ptv3_subm_neighbors": (c_int, [P, c_int64, P, c_int64, c_int, P, P]),

@@ -145,6 +145,29 @@ def window_attention(qkv, win_order, win_inverse, heads, patch, scale, rpe_bias=
     return out
 
 
+def window_attention_rpe(qkv, win_order, win_inverse, heads, patch, scale, grid_coord, rpe_table, pos_bnd):
+    """window_attention() + the RPE bias looked up from the (3*(2*pos_bnd+1), heads) table inside the kernel.
+    Returns None when the window does not fit the resident-window kernel (caller falls back to the dense bias)."""
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    _chk(grid_coord, "grid_coord", torch.int32, 2)
+    _chk(rpe_table, "rpe_table", torch.float32, 2)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    if win_inverse.shape[0] != n or tuple(grid_coord.shape) != (n, 3) or \
+            tuple(rpe_table.shape) != (3 * (2 * pos_bnd + 1), heads):
+        raise RuntimeError("window_attention_rpe: shape mismatch")
+    out = torch.empty((n, c), dtype=qkv.dtype, device=qkv.device)
+    rc = lib.ptv3_window_attn_rpe_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(out), n, win_order.shape[0], c,
+                                      int(heads), int(patch), float(scale), _p(grid_coord), _p(rpe_table),
+                                      int(pos_bnd), _dt(qkv), _stream())
+    if rc == 3:   # PTV3_ERR_UNSUPPORTED
+        return None
+    lib.check(rc, "ptv3_window_attn_rpe_fwd")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # sparse conv support + the implicit GEMM
 # ---------------------------------------------------------------------------------------------

@@ -156,6 +156,19 @@ def test_window_attention_rpe(dev, golden_dir):
                                rpe_bias=bias.to(dev))
     proj = ops.gemm(out, to(c["w"]["proj.weight"].numpy()), bias=to(c["w"]["proj.bias"].numpy()))
     assert (proj.cpu() - torch.from_numpy(c["out"])).abs().max().item() < FP32_TOL
+    # the same bias looked up from the table inside the kernel (no (windows, H, K, K) tensor)
+    pos_bnd = int((4 * c["pmax"]) ** (1 / 3) * 2)
+    out2 = ops.window_attention_rpe(to(c["qkv"]), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5,
+                                    to(c["gc"]).int().contiguous(), c["w"]["rpe.rpe_table"].float().contiguous().to(dev),
+                                    pos_bnd)
+    assert out2 is not None
+    assert (out2.cpu() - out.cpu()).abs().max().item() < 1e-5
+    proj2 = ops.gemm(out2, to(c["w"]["proj.weight"].numpy()), bias=to(c["w"]["proj.bias"].numpy()))
+    assert (proj2.cpu() - torch.from_numpy(c["out"])).abs().max().item() < FP32_TOL
+    out16 = ops.window_attention_rpe(to(c["qkv"]).bfloat16(), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5,
+                                     to(c["gc"]).int().contiguous(),
+                                     c["w"]["rpe.rpe_table"].float().contiguous().to(dev), pos_bnd)
+    assert (out16.float().cpu() - out.cpu()).abs().max().item() < 3e-2
 
 
 # ------------------------------------------------------------------------------------------------
@@ -808,3 +821,33 @@ def test_layernorm_slabs(dev):
     y, y2 = ops.layernorm_slabs(d(slab), splits, m, c, d(bias), torch.float32, d(g1), d(b1), 1e-5, res=d(res),
                                 gamma2=d(g2), beta2=d(b2))
     assert (y.cpu() - y_ref).abs().max().item() < FP32_TOL and (y2.cpu() - y2_ref).abs().max().item() < FP32_TOL
+
+
+def test_model_with_rpe_vs_oracle(dev):
+    """enable_rpe=True (configs/s3dis/semseg-pt-v3m1-1-rpe.py style): every block's attention adds the relative
+    position bias; the HIP model evaluates it inside the attention kernel, the oracle as the reference does."""
+    from pointcept.models import build_model
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    cfg = dict(TINY_CFG, enable_rpe=True)
+    torch.manual_seed(11)
+    model = build_model(dict(type="PT-v3m1", **cfg)).eval()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("rpe_table"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)   # trunc_normal(0.02) would hide the bias
+    for n, b in model.named_buffers():
+        if n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    data = S.make_batch([1800, 1200], in_channels=4, extent=48, seed=13)
+    orc = O.PTv3Oracle(cfg, sd)
+    torch.manual_seed(2)
+    with torch.no_grad():
+        ref = orc.backbone(data)["feat"]
+    model = model.to(dev)
+    torch.manual_seed(2)
+    with torch.no_grad():
+        out = model({k: v.to(dev) for k, v in data.items()}).feat
+    assert (out.cpu() - ref).abs().max().item() < FP32_TOL
