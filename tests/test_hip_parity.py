@@ -851,3 +851,31 @@ def test_model_with_rpe_vs_oracle(dev):
     with torch.no_grad():
         out = model({k: v.to(dev) for k, v in data.items()}).feat
     assert (out.cpu() - ref).abs().max().item() < FP32_TOL
+
+
+@pytest.mark.parametrize("sizes", [[40, 17, 3], [2], [70, 1], [129, 64, 65]])
+def test_tiny_and_ragged_scenes_vs_oracle(dev, sizes):
+    """Degenerate batches: scenes far below the patch size (K shrinks to the smallest scene, down to 1-2 points),
+    levels that pool to a single point, windows with more borrowed than own rows - module path and native executor
+    against the oracle."""
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    torch.manual_seed(21)
+    model = _build(TINY_CFG, hidden_dim=32).eval()
+    gen = torch.Generator().manual_seed(5)
+    for n, b in model.named_buffers():
+        if n.endswith("running_var"):
+            b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    data = S.make_batch(sizes, in_channels=4, extent=12, seed=sum(sizes), with_target=6)
+    orc = O.OffsetKeypointOracle(TINY_CFG, sd)
+    torch.manual_seed(4)
+    with torch.no_grad():
+        ref = orc.forward(data)
+    model = model.to(dev)
+    for use_engine in (True, False):
+        model.backbone.use_engine = use_engine
+        torch.manual_seed(4)
+        with torch.no_grad():
+            out = model({k: v.to(dev) for k, v in data.items()})
+        assert (out["pred"].cpu() - ref["pred"]).abs().max().item() < FP32_TOL, use_engine
