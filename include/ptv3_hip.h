@@ -271,6 +271,12 @@ typedef struct {
   const void* raw_feat;                         /* overlap mode, optional: (n, raw_feat_channels) features still in   */
   int32_t raw_feat_channels;                    /* their original dtype / width; the executor pads them to            */
   int32_t raw_feat_dtype;                       /* desc->in_channels and casts to desc->dtype on its own stream       */
+  int64_t arena_n;                              /* > 0: the workspace was sized by ptv3_forward_workspace_bytes(desc,  */
+  int32_t arena_b;                              /* arena_n, arena_b) with arena_n >= n, arena_b >= b: the four arena    */
+                                                /* parts then sit at offsets that depend on (arena_n, arena_b) only.   */
+                                                /* REQUIRED whenever calls may still be in flight (inputs_resident /    */
+                                                /* overlap_calls) and scene sizes vary: with 0 the parts are laid out   */
+                                                /* for THIS call's n and would move under the previous call's kernels.  */
 } ptv3_forward_io;
 
 size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b);  /* sized for overlap_calls too */

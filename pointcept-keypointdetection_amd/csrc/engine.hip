@@ -554,6 +554,17 @@ extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* para
   PTV3_REQUIRE(io->raw_feat == nullptr || (io->raw_feat_channels >= 1 && io->raw_feat_channels <= desc->in_channels &&
                                            (io->raw_feat_dtype == PTV3_F32 || io->raw_feat_dtype == PTV3_BF16)),
                "forward: bad raw_feat description");
+  if (io->arena_n > 0) {
+    // fixed layout: the parts are placed for the capacity the workspace was sized with, not for this call's n
+    PTV3_REQUIRE(io->arena_n >= io->n && io->arena_b >= io->b, "forward: arena capacity (%lld, %d) below this call (%lld, %d)",
+                 (long long)io->arena_n, io->arena_b, (long long)io->n, io->b);
+    size_t gc, fc;
+    plan_bytes(desc, io->arena_n, io->arena_b, &gc, &fc, nullptr);
+    PTV3_REQUIRE(gc >= g && fc >= f, "forward: arena capacity plan smaller than this call's plan");
+    g = gc; f = fc;
+  } else {
+    PTV3_REQUIRE(!io->inputs_resident || !overlap, "forward: overlap_calls needs a fixed arena layout (arena_n / arena_b)");
+  }
   const size_t need = 2 * g + (overlap ? 2 : 1) * f + 256;
   PTV3_REQUIRE(workspace_bytes >= need, "forward: workspace %zu bytes < %zu (ptv3_forward_workspace_bytes)",
                workspace_bytes, need);
@@ -572,7 +583,16 @@ extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* para
       return PTV3_ERR_LAUNCH;
     }
     sf = g_feat_stream[par];
-    event_at(33);
+    event_at(34);
+    static bool last_overlap = false;
+    if (!last_overlap) {
+      // first overlapped call after stream-ordered ones: those ran their feature pipeline on the caller's stream out
+      // of the first feature arena - order the executor's streams behind them once
+      (void)hipEventRecord(event_at(34), caller);
+      for (int q = 0; q < 2; ++q)
+        if (g_feat_stream[q]) (void)hipStreamWaitEvent(g_feat_stream[q], event_at(34), 0);
+      last_overlap = true;
+    }
     // the output buffers this call overwrites were last read by work the caller enqueued before the PREVIOUS call
     // started (contract in the header): wait for that marker, never for the previous call itself
     (void)hipStreamWaitEvent(sf, event_at(30 + (par ^ 1)), 0);

@@ -2,6 +2,7 @@
 // HBM-bound integer work: one pass over coordinates for the codes, (passes x 3) short kernels
 // for the sort.  Reference semantics: include/ptv3_hip.h.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -118,14 +119,43 @@ __global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ 
   }
 }
 
-// mode 0: first pass (values are implicit iota), 1: middle, 2: last (writes int64 order + inverse)
-template <bool FIRST, bool LAST>
+// FIRST: values are the implicit iota; LAST: writes int64 order + inverse.
+// SCAN: `hist` still holds the raw per-block digit counts and every block derives its own digit bases from them
+// (digit totals over all blocks, scanned across the 256 threads, plus the counts of the blocks before it) - the
+// separate scan launch disappears.  Each block reads nblk*256 counters, so the host only picks this form for
+// nblk <= RS_FUSED_SCAN_MAX_BLOCKS (every level of a 100k-point scene: nblk <= 49).
+constexpr int RS_FUSED_SCAN_MAX_BLOCKS = 128;
+
+template <bool FIRST, bool LAST, bool SCAN>
 __global__ void __launch_bounds__(RS_THREADS)
 radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                      int64_t* __restrict__ order, int64_t* __restrict__ inverse, int64_t n, int shift,
                      const uint32_t* __restrict__ hist, int nblk) {
   __shared__ uint32_t cnt[RS_WAVES][256];  // running per-wave digit counts, then wave bases
+  __shared__ uint32_t gbase[256];
+  __shared__ uint32_t wsum[RS_WAVES];
+  if (SCAN) {
+    const uint32_t* hr = hist + (int64_t)blockIdx.y * nblk * 256 + threadIdx.x;   // digit = threadIdx.x
+    uint32_t total = 0, before = 0;
+    for (int b = 0; b < nblk; ++b) {
+      const uint32_t c = hr[(int64_t)b * 256];
+      total += c;
+      if (b < (int)blockIdx.x) before += c;
+    }
+    uint32_t x = total;
+    const int ln = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t t = __shfl_up(x, d, 64);
+      if (ln >= d) x += t;
+    }
+    if (ln == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t excl = x - total;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) excl += wsum[w];
+    gbase[threadIdx.x] = excl + before;
+  }
   const int row = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t* kin = keys_in + (int64_t)row * n;
@@ -178,7 +208,7 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __res
     int64_t i = wbase + r * 64 + lane;
     if (i < n) {
       uint32_t d = (uint32_t)((key[r] >> shift) & 255);
-      int64_t pos = (int64_t)hrow[d] + cnt[wave][d] + rank[r];
+      int64_t pos = (int64_t)(SCAN ? gbase[d] : hrow[d]) + cnt[wave][d] + rank[r];
       uint32_t v = FIRST ? (uint32_t)i : vals_in[(int64_t)row * n + i];
       if (LAST) {
         order[(int64_t)row * n + pos] = (int64_t)v;
@@ -372,21 +402,21 @@ extern "C" int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_b
     const int shift = 8 * p;
     const bool first = p == 0, last = p == passes - 1;
     hipLaunchKernelGGL(radix_hist_kernel, grid, block, 0, s, kin, n, shift, hist, nblk);
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(k), dim3(256), 0, s, hist, nblk);
+    static const bool allow_fused = getenv("PTV3_RADIX_SEPARATE_SCAN") == nullptr;
+    const bool fused = allow_fused && nblk <= RS_FUSED_SCAN_MAX_BLOCKS;
+    if (!fused) hipLaunchKernelGGL(radix_scan_kernel, dim3(k), dim3(256), 0, s, hist, nblk);
     uint64_t* kout = kbuf[p & 1];
     uint32_t* vout = vbuf[p & 1];
-    if (first && last)
-      hipLaunchKernelGGL((radix_scatter_kernel<true, true>), grid, block, 0, s, kin, vin, kout, vout, order,
-                         inverse, n, shift, hist, nblk);
-    else if (first)
-      hipLaunchKernelGGL((radix_scatter_kernel<true, false>), grid, block, 0, s, kin, vin, kout, vout, order,
-                         inverse, n, shift, hist, nblk);
-    else if (last)
-      hipLaunchKernelGGL((radix_scatter_kernel<false, true>), grid, block, 0, s, kin, vin, kout, vout, order,
-                         inverse, n, shift, hist, nblk);
-    else
-      hipLaunchKernelGGL((radix_scatter_kernel<false, false>), grid, block, 0, s, kin, vin, kout, vout, order,
-                         inverse, n, shift, hist, nblk);
+#define RS_SCATTER(F, L)                                                                                          \
+    if (fused) hipLaunchKernelGGL((radix_scatter_kernel<F, L, true>), grid, block, 0, s, kin, vin, kout, vout, order, \
+                                  inverse, n, shift, hist, nblk);                                                 \
+    else hipLaunchKernelGGL((radix_scatter_kernel<F, L, false>), grid, block, 0, s, kin, vin, kout, vout, order,  \
+                            inverse, n, shift, hist, nblk)
+    if (first && last) { RS_SCATTER(true, true); }
+    else if (first) { RS_SCATTER(true, false); }
+    else if (last) { RS_SCATTER(false, true); }
+    else { RS_SCATTER(false, false); }
+#undef RS_SCATTER
     kin = kout;
     vin = vout;
   }

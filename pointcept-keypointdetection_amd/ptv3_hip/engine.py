@@ -25,7 +25,8 @@ class ForwardIO(ctypes.Structure):
                 ("code", c_void_p), ("order", c_void_p), ("inverse", c_void_p), ("out_feat", c_void_p),
                 ("out_head", c_void_p), ("stage_points_host", POINTER(c_int64)), ("depth_out", POINTER(c_int32)),
                 ("batch_out", c_void_p), ("inputs_resident", c_int32), ("overlap_calls", c_int32),
-                ("raw_feat", c_void_p), ("raw_feat_channels", c_int32), ("raw_feat_dtype", c_int32)]
+                ("raw_feat", c_void_p), ("raw_feat_channels", c_int32), ("raw_feat_dtype", c_int32),
+                ("arena_n", c_int64), ("arena_b", c_int32)]
 
 
 def declare(dll):
@@ -258,16 +259,25 @@ def forward(backbone, point, dtype, head=None):
     else:
         out_feat = torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev)
         out_head = torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None
-    ws_bytes = dll.ptv3_forward_workspace_bytes(ctypes.byref(desc), n, nb)
+    # grow-only arena with a FIXED internal layout (arena_n / arena_b): earlier calls may still be executing out of
+    # it (inputs_resident / overlap_calls), so its parts must not move with the scene size, and it is only replaced
+    # after the device has drained
     arena = backbone.__dict__.get("_engine_arena")
-    if arena is None or arena.numel() < ws_bytes or arena.device != dev:
+    cap = backbone.__dict__.get("_engine_arena_cap", (0, 0, None, None))
+    if arena is None or cap[0] < n or cap[1] < nb or cap[2] != dtype or cap[3] != dev:
+        cap = (max(n, int(cap[0] * 1.25)), max(nb, cap[1]), dtype, dev)
+        ws_bytes = dll.ptv3_forward_workspace_bytes(ctypes.byref(desc), cap[0], cap[1])
+        torch.cuda.synchronize(dev)
+        backbone.__dict__["_engine_arena"] = None
         arena = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        backbone.__dict__["_engine_arena"] = arena
+        torch.cuda.synchronize(dev)
+        backbone.__dict__["_engine_arena"], backbone.__dict__["_engine_arena_cap"] = arena, cap
     stage_pts = (c_int64 * 8)()
     io = ForwardIO()
     io.grid_coord, io.coord_is_i64 = gc.data_ptr(), int(gc.dtype == torch.int64)
     io.feat, io.offset = feat.data_ptr(), offset.data_ptr()
     io.overlap_calls = int(overlap)
+    io.arena_n, io.arena_b = cap[0], cap[1]
     if raw is not None:
         io.raw_feat, io.raw_feat_channels = raw.data_ptr(), raw.shape[1]
         io.raw_feat_dtype = PTV3_F32 if raw.dtype == torch.float32 else PTV3_BF16
