@@ -62,6 +62,10 @@ class Packed:
     def fresh(self):
         v = [t._version for t in self.sources]
         if v != self.versions:
+            if self.tensors is not None:
+                # earlier forwards may still be reading the old packed copies (inputs_resident / overlap_calls run
+                # ahead of the caller's stream): drain the device before they are released and their memory reused
+                torch.cuda.synchronize()
             with torch.no_grad():
                 self.tensors = self._pack()
             self.table = (c_void_p * len(self.tensors))(*[t.data_ptr() for t in self.tensors])
