@@ -262,7 +262,51 @@ class Block(PointModule):
         point.sparse_conv_feat = spt.replace_feature(feat)
         return point
 
+    def _train_fusable(self):
+        mlp = self.mlp[0]
+        drops = [self.attn.proj_drop, mlp.drop] + ([self.attn.attn_drop] if isinstance(self.attn.attn_drop, nn.Dropout) else [])
+        return (self._fusable() and isinstance(mlp.act, nn.GELU) and not self.attn.enable_rpe
+                and all(d.p == 0.0 for d in drops) and self.cpe[0].bias is not None
+                and self.cpe[2].eps == self.norm1[0].eps == self.norm2[0].eps
+                and isinstance(self.drop_path[0], (DropPath, nn.Identity)))
+
+    def _drop_mask(self, feat):
+        """per-point DropPath factor (timm drop_path on the (N, C) matrix), or None"""
+        dp = self.drop_path[0]
+        if not isinstance(dp, DropPath) or dp.drop_prob == 0.0:
+            return None
+        keep = 1.0 - dp.drop_prob
+        mask = feat.new_empty((feat.shape[0], 1)).bernoulli_(keep)
+        if keep > 0.0 and dp.scale_by_keep:
+            mask.div_(keep)
+        return mask
+
+    def _forward_train(self, point: Point):
+        """Training: the whole block as ONE taped Function (ptv3_hip.autograd.BlockFn) - same kernels and statement
+        order as _forward_generic, without a trip through the autograd engine per layer."""
+        spt = point.sparse_conv_feat
+        feat = point.feat
+        conv_feat = None if spt.features is feat else spt.features
+        mlp = self.mlp[0]
+        K = self.attn.resolve_patch_size(point)
+        wo, wi = self.attn.window_maps(point)
+        params = (self.cpe[0].weight, self.cpe[0].bias, self.cpe[1].weight, self.cpe[1].bias, self.cpe[2].weight,
+                  self.cpe[2].bias, self.norm1[0].weight, self.norm1[0].bias, self.attn.qkv.weight, self.attn.qkv.bias,
+                  self.attn.proj.weight, self.attn.proj.bias, self.norm2[0].weight, self.norm2[0].bias,
+                  mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)
+        # the two DropPath draws in the reference's order: attention branch, then MLP branch
+        mask1 = self._drop_mask(feat)
+        mask2 = self._drop_mask(feat)
+        out = A.block(feat, conv_feat, params, spt.neighbors(3, self.cpe[0].indice_key), spt.row_order, wo, wi,
+                      self.attn.num_heads, K, self.attn.scale, mask1, mask2, self.cpe[2].eps)
+        point.feat = out
+        point.sparse_conv_feat = spt.replace_feature(out)
+        return point
+
     def forward(self, point: Point):
+        if self.training and self._train_fusable() and point.feat.shape[1] % ops.k_granule(point.feat.dtype) == 0 \
+                and self.attn.qkv.bias is not None:
+            return self._forward_train(point)
         if self.training or not self._fusable():
             return self._forward_generic(point)
         mlp = self.mlp[0]

@@ -258,3 +258,103 @@ def segment_max(feat, order0, seg_start, n_out):
 
 def cluster_gather(feat, cluster, order0, seg_start):
     return ClusterGatherFn.apply(feat, cluster, order0, seg_start)
+
+
+# -------------------------------------------------------------------------------------------------
+# One Function per Block for training: the same kernels as the per-layer Functions above, issued back to back
+# without going through the autograd engine between them (13 Function round trips per block become one).
+# -------------------------------------------------------------------------------------------------
+def _lin_fwd(x, w, b):
+    return ops.gemm(x, w, bias=None if b is None else b.detach().float().contiguous())
+
+
+def _lin_bwd(dy, x, w_cast, gran):
+    """-> dx, dW (fp32, (cout, cin)), db (fp32) of y = x w^T + b; w_cast (cout, cin) in the activation dtype."""
+    dx = ops.gemm(_pad_cols(dy, gran), _pad_cols(w_cast.t().contiguous(), gran))
+    return dx, ops.gemm_tn(dy, x), ops.col_reduce(dy)
+
+
+class BlockFn(Function):
+    """Block.forward (point_transformer_v3m1_base.py:318-338, pre-norm form) with LayerNorm / GELU layers:
+      c  = LN0(lin(conv(conv_feat)));  f1 = feat + c
+      f2 = f1 + mask1 * proj(attn(qkv(LN1(f1))))
+      out = f2 + mask2 * fc2(GELU(fc1(LN2(f2))))
+    mask1 / mask2 are the per-point DropPath factors (None when drop_path = 0).  `conv_feat` is the tensor the
+    xCPE conv reads: `feat` itself, except in the first decoder block, where the reference leaves the sparse tensor
+    on the skip branch (see SerializedUnpooling)."""
+
+    @staticmethod
+    def forward(ctx, feat, conv_feat, conv_w, conv_b, lin_w, lin_b, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b,
+                proj_w, proj_b, n2_g, n2_b, fc1_w, fc1_b, fc2_w, fc2_b, nbr, row_order, wo, wi, heads, patch, scale,
+                mask1, mask2, eps):
+        dt = feat.dtype
+        feat = feat.contiguous()
+        same = conv_feat is None
+        xin = feat if same else conv_feat.contiguous()
+        kvol = nbr.shape[1]
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        w_conv = _wmat(conv_w, dt)
+        w_lin, w_qkv, w_proj = _wmat(lin_w, dt), _wmat(qkv_w, dt), _wmat(proj_w, dt)
+        w_fc1, w_fc2 = _wmat(fc1_w, dt), _wmat(fc2_w, dt)
+        c1 = ops.gemm(xin, w_conv, bias=f32(conv_b), nbr=nbr, kvol=kvol, row_order=row_order)
+        c2 = _lin_fwd(c1, w_lin, lin_b)
+        f1 = ops.layernorm(c2, f32(ln0_g), f32(ln0_b), eps, res=feat)
+        t3 = ops.layernorm(f1, f32(n1_g), f32(n1_b), eps)
+        qkv = _lin_fwd(t3, w_qkv, qkv_b)
+        a = ops.window_attention(qkv, wo, wi, heads, patch, scale)
+        p = _lin_fwd(a, w_proj, proj_b)
+        f2 = f1 + (p if mask1 is None else p * mask1)
+        t5 = ops.layernorm(f2, f32(n2_g), f32(n2_b), eps)
+        h0 = _lin_fwd(t5, w_fc1, fc1_b)
+        h = ops.affine_act(h0, None, None, ops.ACT_GELU)
+        m = _lin_fwd(h, w_fc2, fc2_b)
+        out = f2 + (m if mask2 is None else m * mask2)
+        ctx.save_for_backward(xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2,
+                              conv_w, ln0_g, n1_g, n2_g)
+        ctx.cast = (w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2)
+        ctx.cfg = (heads, patch, scale, eps, same)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2, conv_w, ln0_g, n1_g,
+         n2_g) = ctx.saved_tensors
+        w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2 = ctx.cast
+        heads, patch, scale, eps, same = ctx.cfg
+        dt = dout.dtype
+        gran = ops.k_granule(dt)
+        pd = conv_w.dtype
+        dout = dout.contiguous()
+        f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
+        # ---- MLP branch
+        dm = dout if mask2 is None else dout * mask2
+        dh, dW_fc2, db_fc2 = _lin_bwd(dm, h, w_fc2, gran)
+        dh0 = ops.act_bwd(dh, h0, ops.ACT_GELU)
+        dt5, dW_fc1, db_fc1 = _lin_bwd(dh0, t5, w_fc1, gran)
+        dx, dg2, db2 = ops.layernorm_bwd(f2, dt5, f32(n2_g), eps)
+        df2 = dout + dx
+        # ---- attention branch
+        dp = df2 if mask1 is None else df2 * mask1
+        da, dW_proj, db_proj = _lin_bwd(dp, a, w_proj, gran)
+        dqkv = ops.window_attention_bwd(qkv, a, da.contiguous(), wo, wi, heads, patch, scale)
+        dt3, dW_qkv, db_qkv = _lin_bwd(dqkv, t3, w_qkv, gran)
+        dx, dg1, db1 = ops.layernorm_bwd(f1, dt3, f32(n1_g), eps)
+        df1 = df2 + dx
+        # ---- xCPE branch
+        dc2, dg0, db0 = ops.layernorm_bwd(c2, df1, f32(ln0_g), eps)
+        dc1, dW_lin, db_lin = _lin_bwd(dc2, c1, w_lin, gran)
+        kvol = nbr.shape[1]
+        cout, cin = conv_w.shape[0], conv_w.shape[-1]
+        wt = w_conv.view(cout, kvol, cin).flip(1).permute(2, 1, 0).reshape(cin, -1).contiguous()
+        dxin = ops.gemm(_pad_cols(dc1, gran), wt, nbr=nbr, kvol=kvol, row_order=row_order)
+        dW_conv = ops.gemm_tn(dc1, xin, nbr, kvol).view(conv_w.shape)
+        db_conv = ops.col_reduce(dc1)
+        dfeat = df1 + dxin if same else df1
+        c = lambda t: t.to(pd)  # noqa: E731
+        return (dfeat, None if same else dxin, c(dW_conv), c(db_conv), c(dW_lin), c(db_lin), c(dg0), c(db0), c(dg1),
+                c(db1), c(dW_qkv), c(db_qkv), c(dW_proj), c(db_proj), c(dg2), c(db2), c(dW_fc1), c(db_fc1), c(dW_fc2),
+                c(db_fc2), None, None, None, None, None, None, None, None, None, None)
+
+
+def block(feat, conv_feat, blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps):
+    return BlockFn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps)
