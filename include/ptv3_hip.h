@@ -155,7 +155,7 @@ int ptv3_block_head(const void* x, const float* slab, int splits, const float* c
 /* Row-local two-layer MLP, hidden layer in registers (the dense keypoint head, offset_keypoint_ptv3.py:26-31:
  * Linear -> BatchNorm1d(eval) -> ReLU -> Linear):  out = act((x @ w1^T + b1) * s1 + t1) @ w2^T + b2.
  * x (m, cin) dtype, cin in {32, 64}; w1 (hidden, cin) natural; b1 / s1 / t1 (hidden) fp32 (each optional: 0 / 1 / 0);
- * w2 (ceil16(cout), hidden) with zero rows beyond cout and, for bf16, its input channels chain-permuted exactly like
+ * w2 (16 | 32 | 64 rows for cout <= 16 | 32 | 64, hidden) with zero rows beyond cout and, for bf16, its input channels chain-permuted exactly like
  * ptv3_block_tail's w2; b2 (cout) fp32; out (m, cout) fp32 when out_f32 else dtype.  hidden % 64 == 0, cout % 4 == 0,
  * cout <= 64 (ptv3_mlp2_fusable). */
 int ptv3_mlp2_fusable(int cin, int hidden, int cout, int dtype);

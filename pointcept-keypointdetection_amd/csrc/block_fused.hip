@@ -19,6 +19,7 @@
 #include "common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
 
@@ -81,17 +82,42 @@ __device__ __forceinline__ void row_norm(const f32x4* v, float eps, float& mean,
   rstd = rsqrtf(groups_sum(q) * (1.0f / (16 * NT)) + eps);
 }
 
-template <typename T, int NT>
+template <typename T> struct WPad { static constexpr int V = 16 / sizeof(T); };
+
+template <typename T>
+__device__ __forceinline__ void stage_matrix(T* dst, const T* __restrict__ src, int rows, int cols, int ld) {
+  typedef typename Frag<T>::type FR;
+  constexpr int E = Frag<T>::E;
+  const int cpr = cols / E;
+  for (int u = threadIdx.x; u < rows * cpr; u += blockDim.x) {
+    const int r = u / cpr, ch = u % cpr;
+    *reinterpret_cast<FR*>(dst + r * ld + E * ch) = *reinterpret_cast<const FR*>(src + (int64_t)r * cols + E * ch);
+  }
+}
+
+template <typename T, int NT, bool WLDS>
 __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
   typedef typename Vec4<T>::type V4;
   constexpr int C = 16 * NT, E = F::E, KC = F::KC;
   constexpr int NKC = ChainFrag<T, NT>::NKC;
+  extern __shared__ __attribute__((aligned(16))) char head_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * 16 + li;
-  if (((int64_t)blockIdx.x * 4 + wave) * 16 >= a.m) return;  // whole wave out of range
+  const T* w = reinterpret_cast<const T*>(a.wqkv);
+  int ldc = C;
+  if (WLDS) {   // the 3C x C qkv weight resident in LDS for all row blocks of this workgroup
+    ldc = C + WPad<T>::V;
+    T* sW = reinterpret_cast<T*>(head_smem);
+    stage_matrix<T>(sW, w, 3 * C, C, ldc);
+    __syncthreads();
+    w = sW;
+  }
+  const int64_t nblocks = (a.m + 63) / 64;
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  const int64_t row = (blk * 4 + wave) * 16 + li;
+  if ((blk * 4 + wave) * 16 >= a.m) continue;  // whole wave out of range
   const bool valid = row < a.m;
   const int64_t rc = valid ? row : a.m - 1;
   const T* sc = reinterpret_cast<const T*>(a.shortcut);
@@ -138,7 +164,6 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
   for (int kc = 0; kc < NKC; ++kc) xf[kc] = ChainFrag<T, NT>::get(v, kc);
 
   // qkv = t3 @ Wqkv^T + b : 3*NT output tiles, 4 at a time
-  const T* w = reinterpret_cast<const T*>(a.wqkv);
   T* qkv = reinterpret_cast<T*>(a.qkv);
   constexpr int OT = 3 * NT;
   for (int o0 = 0; o0 < OT; o0 += 4) {
@@ -150,7 +175,7 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
         if (o0 + jj < OT) {
-          FR wa = *reinterpret_cast<const FR*>(w + (int64_t)(16 * (o0 + jj) + li) * C + KC * kc + E * g);
+          FR wa = *reinterpret_cast<const FR*>(w + (16 * (o0 + jj) + li) * ldc + KC * kc + E * g);
           acc[jj] = F::mma(wa, xf[kc], acc[jj]);
         }
 #pragma unroll
@@ -162,11 +187,15 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
             pack4<T>(acc[jj][0] + b[0], acc[jj][1] + b[1], acc[jj][2] + b[2], acc[jj][3] + b[3]);
       }
   }
+  }  // row blocks
 }
 
 // RT = 16-point row tiles per wave: every weight fragment fetched from L1/L2 feeds RT matrix-core steps and the
 // RT chains are independent (the single-tile form is latency-bound: one MFMA per fragment load).
-template <typename T, int NT, int RT>
+// WLDS: the 9*C^2 weights are staged once per workgroup into LDS (rows padded by 16 bytes) and the workgroup walks
+// row blocks in a grid-stride loop: without it every wave re-streams all weights from L2 (72 KB per 32 points at
+// C = 64: 225 MB of L2 traffic per 100k-point call, the real bound of the first version).
+template <typename T, int NT, int RT, bool WLDS>
 __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
@@ -174,21 +203,37 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   constexpr int C = 16 * NT, E = F::E, KC = F::KC;
   constexpr int NKC = ChainFrag<T, NT>::NKC;
   constexpr int HKC = 64 / KC;  // K-chunks per 64-wide hidden slice (2 bf16 / 4 fp32)
+  extern __shared__ __attribute__((aligned(16))) char tail_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
-  if (base >= a.m) return;
+  const T* attn = reinterpret_cast<const T*>(a.attn);
+  const T* f1 = reinterpret_cast<const T*>(a.f1);
+  const T* wp = reinterpret_cast<const T*>(a.wproj);
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+  const T* w2 = reinterpret_cast<const T*>(a.w2);
+  int ldc = C, ldh = a.hidden;   // row strides of (wproj, w1) and of w2
+  if (WLDS) {
+    ldc = C + WPad<T>::V;
+    ldh = a.hidden + WPad<T>::V;
+    T* sWp = reinterpret_cast<T*>(tail_smem);
+    T* sW1 = sWp + C * ldc;
+    T* sW2 = sW1 + a.hidden * ldc;
+    stage_matrix<T>(sWp, wp, C, C, ldc);
+    stage_matrix<T>(sW1, w1, a.hidden, C, ldc);
+    stage_matrix<T>(sW2, w2, C, a.hidden, ldh);
+    __syncthreads();
+    wp = sWp; w1 = sW1; w2 = sW2;
+  }
+  const int64_t nblocks = (a.m + 64 * RT - 1) / (64 * RT);
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  const int64_t base = (blk * 4 + wave) * (16 * RT);
+  if (base >= a.m) continue;
   int64_t row[RT], rc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     row[t] = base + 16 * t + li;
     rc[t] = row[t] < a.m ? row[t] : a.m - 1;
   }
-  const T* attn = reinterpret_cast<const T*>(a.attn);
-  const T* f1 = reinterpret_cast<const T*>(a.f1);
-  const T* wp = reinterpret_cast<const T*>(a.wproj);
-  const T* w1 = reinterpret_cast<const T*>(a.w1);
-  const T* w2 = reinterpret_cast<const T*>(a.w2);
 
   // ---- f2 = attn @ Wproj^T + b + f1   (attn rows are in natural channel order: natural Wproj)
   f32x4 f2[RT][NT];
@@ -203,7 +248,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
     for (int t = 0; t < RT; ++t) xb[t] = *reinterpret_cast<const FR*>(attn + rc[t] * C + KC * kc + E * g);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      FR wa = *reinterpret_cast<const FR*>(wp + (int64_t)(16 * j + li) * C + KC * kc + E * g);
+      FR wa = *reinterpret_cast<const FR*>(wp + (16 * j + li) * ldc + KC * kc + E * g);
 #pragma unroll
       for (int t = 0; t < RT; ++t) f2[t][j] = F::mma(wa, xb[t], f2[t][j]);
     }
@@ -247,14 +292,14 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(16 * jj + li) * C + KC * kc + E * g);
+      w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (16 * jj + li) * ldc + KC * kc + E * g);
   for (int h0 = 0; h0 < a.hidden; h0 += 64) {
     FR w2f[HKC][NT];
 #pragma unroll
     for (int mm = 0; mm < HKC; ++mm)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+        w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (16 * j + li) * ldh + h0 + KC * mm + E * g);
     f32x4 bias1[4];
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) bias1[jj] = *reinterpret_cast<const f32x4*>(a.bias1 + h0 + 16 * jj + 4 * g);
@@ -274,7 +319,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
     for (int kc = 0; kc < NKC; ++kc)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(hn + 16 * jj + li) * C + KC * kc + E * g);
+        w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (hn + 16 * jj + li) * ldc + KC * kc + E * g);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -305,6 +350,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
                    o[t][j][3] + b[3] + f2[t][j][3]);
     }
   }
+  }  // row blocks
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,20 +365,34 @@ struct Mlp2Args {
   int64_t m; int hidden, cout, act, out_f32;
 };
 
-template <typename T, int NTI, int NTO, int RT>
+template <typename T, int NTI, int NTO, int RT, bool WLDS>
 __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
   typedef typename Vec4<T>::type V4;
   constexpr int CI = 16 * NTI, E = F::E, KC = F::KC;
   constexpr int HKC = 64 / KC;
+  extern __shared__ __attribute__((aligned(16))) char mlp_smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
-  if (base >= a.m) return;
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* w1 = reinterpret_cast<const T*>(a.w1);
   const T* w2 = reinterpret_cast<const T*>(a.w2);
+  int ld1 = CI, ld2 = a.hidden;
+  if (WLDS) {   // both weight matrices resident in LDS for all row blocks of this workgroup
+    ld1 = CI + WPad<T>::V;
+    ld2 = a.hidden + WPad<T>::V;
+    T* sW1 = reinterpret_cast<T*>(mlp_smem);
+    T* sW2 = sW1 + a.hidden * ld1;
+    stage_matrix<T>(sW1, w1, a.hidden, CI, ld1);
+    stage_matrix<T>(sW2, w2, 16 * NTO, a.hidden, ld2);
+    __syncthreads();
+    w1 = sW1; w2 = sW2;
+  }
+  const int64_t nblocks = (a.m + 64 * RT - 1) / (64 * RT);
+  for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  const int64_t base = (blk * 4 + wave) * (16 * RT);
+  if (base >= a.m) continue;
   int64_t row[RT];
   FR xf[RT][CI / KC];
 #pragma unroll
@@ -352,14 +412,14 @@ __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
   for (int kc = 0; kc < CI / KC; ++kc)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
-      w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(16 * jj + li) * CI + KC * kc + E * g);
+      w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (16 * jj + li) * ld1 + KC * kc + E * g);
   for (int h0 = 0; h0 < a.hidden; h0 += 64) {
     FR w2f[HKC][NTO];
 #pragma unroll
     for (int mm = 0; mm < HKC; ++mm)
 #pragma unroll
       for (int j = 0; j < NTO; ++j)
-        w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (int64_t)(16 * j + li) * a.hidden + h0 + KC * mm + E * g);
+        w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (16 * j + li) * ld2 + h0 + KC * mm + E * g);
     f32x4 h[RT][4];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -376,7 +436,7 @@ __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
     for (int kc = 0; kc < CI / KC; ++kc)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (int64_t)(hn + 16 * jj + li) * CI + KC * kc + E * g);
+        w1f[kc][jj] = *reinterpret_cast<const FR*>(w1 + (hn + 16 * jj + li) * ld1 + KC * kc + E * g);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int ch = h0 + 16 * jj + 4 * g;
@@ -417,6 +477,7 @@ __global__ void __launch_bounds__(256) mlp2_kernel(Mlp2Args a) {
       else *reinterpret_cast<V4*>(reinterpret_cast<T*>(a.out) + row[t] * a.cout + ch) = pack4<T>(v[0], v[1], v[2], v[3]);
     }
   }
+  }  // row blocks
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,20 +728,39 @@ static int row_tiles(int64_t m) {
   return m >= 32768 ? 2 : 1;
 }
 
+static size_t tail_wlds_bytes(int c, int hidden, int esz) {
+  const int pad = 16 / esz;
+  return ((size_t)(c + hidden) * (c + pad) + (size_t)c * (hidden + pad)) * esz;
+}
+
+template <typename T, int NT, int RT>
+static void launch_tail(const TailArgs& a, int c, hipStream_t s) {
+  const size_t wb = tail_wlds_bytes(c, a.hidden, sizeof(T));
+  const int64_t nblocks = cdiv(a.m, 64 * RT);
+  if (wb <= 96 * 1024) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_tail_kernel<T, NT, RT, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr = true;
+    }
+    // weights resident per workgroup: a few workgroups per CU, each walking many row blocks
+    const int64_t grid = std::min<int64_t>(nblocks, 2 * 256);
+    hipLaunchKernelGGL((block_tail_kernel<T, NT, RT, true>), dim3((unsigned)grid), dim3(256), wb, s, a);
+  } else {
+    hipLaunchKernelGGL((block_tail_kernel<T, NT, RT, false>), dim3((unsigned)nblocks), dim3(256), 0, s, a);
+  }
+}
+
 #define TAIL_LAUNCH(ARGS)                                                                                \
   {                                                                                                      \
     const int rt = row_tiles(m);                                                                         \
-    dim3 grid((unsigned)cdiv(m, 64 * rt)), block(256);                                                   \
     if (dtype == PTV3_F32) {                                                                             \
-      if (c == 32) { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<float, 2, 2>), grid, block, 0, s, ARGS); \
-                     else hipLaunchKernelGGL((block_tail_kernel<float, 2, 1>), grid, block, 0, s, ARGS); } \
-      else { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<float, 4, 2>), grid, block, 0, s, ARGS);   \
-             else hipLaunchKernelGGL((block_tail_kernel<float, 4, 1>), grid, block, 0, s, ARGS); }         \
+      if (c == 32) { if (rt == 2) launch_tail<float, 2, 2>(ARGS, c, s); else launch_tail<float, 2, 1>(ARGS, c, s); } \
+      else { if (rt == 2) launch_tail<float, 4, 2>(ARGS, c, s); else launch_tail<float, 4, 1>(ARGS, c, s); }         \
     } else {                                                                                             \
-      if (c == 32) { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<__bf16, 2, 2>), grid, block, 0, s, ARGS); \
-                     else hipLaunchKernelGGL((block_tail_kernel<__bf16, 2, 1>), grid, block, 0, s, ARGS); } \
-      else { if (rt == 2) hipLaunchKernelGGL((block_tail_kernel<__bf16, 4, 2>), grid, block, 0, s, ARGS);  \
-             else hipLaunchKernelGGL((block_tail_kernel<__bf16, 4, 1>), grid, block, 0, s, ARGS); }        \
+      if (c == 32) { if (rt == 2) launch_tail<__bf16, 2, 2>(ARGS, c, s); else launch_tail<__bf16, 2, 1>(ARGS, c, s); } \
+      else { if (rt == 2) launch_tail<__bf16, 4, 2>(ARGS, c, s); else launch_tail<__bf16, 4, 1>(ARGS, c, s); }         \
     }                                                                                                    \
   }
 
@@ -777,11 +857,22 @@ extern "C" int ptv3_mlp2(const void* x, const void* w1, const float* b1, const f
                               ((double)m * cin + (double)hidden * (cin + cout)) * esz + (double)m * cout * (out_f32 ? 4 : esz),
                               nullptr, 0, 0.0);
   const int rt = row_tiles(m);
-  dim3 grid((unsigned)cdiv(m, 64 * rt)), block(256);
   const int nto = cout <= 16 ? 1 : cout <= 32 ? 2 : 4;
+  const size_t wb = ((size_t)hidden * (cin + 16 / esz) + (size_t)16 * nto * (hidden + 16 / esz)) * esz;
+  const bool wlds = wb <= 128 * 1024;
+  const int64_t nblocks = cdiv(m, 64 * rt);
+  dim3 grid((unsigned)(wlds ? std::min<int64_t>(nblocks, 2 * 256) : nblocks)), block(256);
+#define MLP2_GO(KERNEL_T, KERNEL_F)                                                               \
+  if (wlds) {                                                                                     \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL_T), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              128 * 1024);                                                        \
+    hipLaunchKernelGGL(KERNEL_T, grid, block, wb, s, a);                                          \
+  } else {                                                                                        \
+    hipLaunchKernelGGL(KERNEL_F, grid, block, 0, s, a);                                           \
+  }
 #define MLP2_RT(T, NTI, NTO)                                                                      \
-  if (rt == 2) hipLaunchKernelGGL((mlp2_kernel<T, NTI, NTO, 2>), grid, block, 0, s, a);           \
-  else hipLaunchKernelGGL((mlp2_kernel<T, NTI, NTO, 1>), grid, block, 0, s, a);
+  if (rt == 2) { MLP2_GO((mlp2_kernel<T, NTI, NTO, 2, true>), (mlp2_kernel<T, NTI, NTO, 2, false>)) } \
+  else { MLP2_GO((mlp2_kernel<T, NTI, NTO, 1, true>), (mlp2_kernel<T, NTI, NTO, 1, false>)) }
 #define MLP2_CASE(T, NTI)                                                                         \
   if (nto == 1) { MLP2_RT(T, NTI, 1) }                                                            \
   else if (nto == 2) { MLP2_RT(T, NTI, 2) }                                                       \
@@ -793,6 +884,7 @@ extern "C" int ptv3_mlp2(const void* x, const void* w1, const float* b1, const f
   }
 #undef MLP2_CASE
 #undef MLP2_RT
+#undef MLP2_GO
   prof_end(prof, s);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
@@ -813,7 +905,16 @@ extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, con
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * 3 * c, ((double)m * c * 6 + 3.0 * c * c) * esz, nullptr, 0, 0.0);
   if (mode == 1) {
-    FUSED_LAUNCH(block_head_kernel, a)
+    const int64_t nblocks = cdiv(m, 64);
+    const size_t wb = (size_t)3 * c * (c + 16 / esz) * esz;
+    const dim3 grid_l((unsigned)std::min<int64_t>(nblocks, 4 * 256)), block(256);
+    if (dtype == PTV3_F32) {
+      if (c == 32) hipLaunchKernelGGL((block_head_kernel<float, 2, true>), grid_l, block, wb, s, a);
+      else hipLaunchKernelGGL((block_head_kernel<float, 4, true>), grid_l, block, wb, s, a);
+    } else {
+      if (c == 32) hipLaunchKernelGGL((block_head_kernel<__bf16, 2, true>), grid_l, block, wb, s, a);
+      else hipLaunchKernelGGL((block_head_kernel<__bf16, 4, true>), grid_l, block, wb, s, a);
+    }
   } else {
     COOP_LAUNCH(launch_head_coop, a)
   }

@@ -288,9 +288,11 @@ def mlp2_fusable(cin, hidden, cout, dtype):
 
 
 def mlp2_weight2(w2, dtype):
-    """(cout, hidden) parameter -> the (ceil16(cout), hidden) chain-permuted matrix ptv3_mlp2 reads."""
+    """(cout, hidden) parameter -> the (16 | 32 | 64, hidden) chain-permuted matrix ptv3_mlp2 reads (rows beyond
+    cout are zero; the kernel works on 1, 2 or 4 output tiles)."""
     w = w2.detach().to(dtype)
-    pad = (-w.shape[0]) % 16
+    rows = 16 if w.shape[0] <= 16 else 32 if w.shape[0] <= 32 else 64
+    pad = rows - w.shape[0]
     if pad:
         w = torch.nn.functional.pad(w, (0, 0, 0, pad))
     return chain_permute(w.contiguous(), dtype)
