@@ -168,7 +168,7 @@ def train_bench(args, model, device, world, rank, local_rank):
     # the fork's optimizer config: AdamW lr 0.002 wd 0.005, "block" parameters at lr 0.0002
     groups = [dict(params=[p for n, p in model.named_parameters() if "block" in n], lr=2e-4),
               dict(params=[p for n, p in model.named_parameters() if "block" not in n])]
-    opt = FusedAdamW(groups, lr=2e-3, weight_decay=5e-3)
+    opt = FusedAdamW(groups, lr=2e-3, weight_decay=5e-3, shadow_dtype=dtype)
     scenes = [S.make_scene(args.points, 4, None, seed, args.kind) for seed in rank_scene_seeds(rank, args.scenes)]
     batch = {k: v.to(device) for k, v in S.collate(scenes, with_target=6).items()}
     n_points = args.points * args.scenes

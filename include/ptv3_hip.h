@@ -337,6 +337,12 @@ size_t ptv3_adamw_entry_bytes(void);
 int ptv3_adamw_chunk(void);
 int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* grad, void* exp_avg, void* exp_avg_sq,
                           int64_t numel, int group, int first_block);
+/* optional, after ptv3_adamw_fill_entry: the step also writes the updated parameter into `shadow` (same layout, fp32 or
+ * bf16) and, when shadow_t is given, into a (cols, kvol mirrored, rows) transposed copy of the (rows, kvol, cols) weight
+ * - W^T of a Linear (kvol 1) / the mirrored-tap weight of a SubMConv3d input gradient - so the training kernels never
+ * cast or transpose weights between steps. */
+int ptv3_adamw_fill_shadow(void* entry_host, void* shadow, void* shadow_t, int rows, int cols, int kvol,
+                           int shadow_dtype);
 int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
                     const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
                     float grad_scale, void* stream);

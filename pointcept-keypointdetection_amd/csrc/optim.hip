@@ -10,6 +10,11 @@ namespace ptv3 {
 struct AdamWTensor {
   float* p; const float* g; float* m; float* v;
   int64_t numel; int32_t group; int32_t first_block;
+  // optional compute-dtype shadows the training Functions read instead of casting / transposing every step:
+  // shadow = the parameter as is; shadow_t = (rows, kvol, cols) -> (cols, kvol mirrored, rows), i.e. W^T for a
+  // Linear (kvol = 1) and the mirrored-tap transposed weight of a SubMConv3d input gradient
+  void* shadow; void* shadow_t;
+  int32_t rows, cols, kvol, shadow_dtype;
 };
 
 struct AdamWGroups { float lr[8], wd[8]; };
@@ -37,6 +42,23 @@ __global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restric
     const float denom = sqrtf(v) * rsqrt_bc2 + eps;
     p -= step * (m / denom);
     t.p[j] = p; t.m[j] = m; t.v[j] = v;
+    if (t.shadow) {
+      int64_t jt = j;
+      if (t.shadow_t) {
+        const int64_t kc = (int64_t)t.kvol * t.cols;
+        const int o = (int)(j / kc);
+        const int d = (int)((j - (int64_t)o * kc) / t.cols);
+        const int c = (int)(j - (int64_t)o * kc - (int64_t)d * t.cols);
+        jt = ((int64_t)c * t.kvol + (t.kvol - 1 - d)) * t.rows + o;
+      }
+      if (t.shadow_dtype == PTV3_BF16) {
+        reinterpret_cast<__bf16*>(t.shadow)[j] = (__bf16)p;
+        if (t.shadow_t) reinterpret_cast<__bf16*>(t.shadow_t)[jt] = (__bf16)p;
+      } else {
+        reinterpret_cast<float*>(t.shadow)[j] = p;
+        if (t.shadow_t) reinterpret_cast<float*>(t.shadow_t)[jt] = p;
+      }
+    }
   }
 }
 
@@ -89,6 +111,19 @@ extern "C" int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* 
   AdamWTensor* e = (AdamWTensor*)entry_host;
   e->p = (float*)param; e->g = (const float*)grad; e->m = (float*)exp_avg; e->v = (float*)exp_avg_sq;
   e->numel = numel; e->group = group; e->first_block = first_block;
+  e->shadow = nullptr; e->shadow_t = nullptr; e->rows = e->cols = e->kvol = 0; e->shadow_dtype = PTV3_F32;
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_adamw_fill_shadow(void* entry_host, void* shadow, void* shadow_t, int rows, int cols, int kvol,
+                                      int shadow_dtype) {
+  PTV3_REQUIRE(shadow != nullptr, "adamw: shadow pointer required");
+  PTV3_REQUIRE(shadow_dtype == PTV3_F32 || shadow_dtype == PTV3_BF16, "adamw: bad shadow dtype");
+  AdamWTensor* e = (AdamWTensor*)entry_host;
+  PTV3_REQUIRE(shadow_t == nullptr || (rows > 0 && cols > 0 && kvol > 0 && (int64_t)rows * cols * kvol == e->numel),
+               "adamw: shadow_t needs rows * kvol * cols == numel");
+  e->shadow = shadow; e->shadow_t = shadow_t; e->rows = rows; e->cols = cols; e->kvol = kvol;
+  e->shadow_dtype = shadow_dtype;
   return PTV3_OK;
 }
 

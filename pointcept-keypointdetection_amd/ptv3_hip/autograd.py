@@ -20,6 +20,18 @@ def _wmat(w, dtype, cin_pad=None):
     return w.reshape(w.shape[0], -1).to(dtype).contiguous()
 
 
+def _weights(weight, dtype, cin_pad=None):
+    """(natural (cout, kvol*cin) matrix, transposed / tap-mirrored (cin, kvol*cout) matrix or None) in `dtype`.
+    With a FusedAdamW(shadow_dtype=...) attached both come from the shadows its step kernel keeps current; otherwise
+    the natural one is cast here and the transposed one is built in backward."""
+    if cin_pad is None or cin_pad == weight.shape[-1]:
+        from .optim import weight_shadow
+        sh = weight_shadow(weight, dtype)
+        if sh is not None:
+            return sh["nat"], sh["t"]
+    return _wmat(weight, dtype, cin_pad), None
+
+
 def _pad_cols(x, gran):
     pad = (-x.shape[1]) % gran
     return torch.nn.functional.pad(x, (0, pad)).contiguous() if pad else x
@@ -32,11 +44,11 @@ class LinearFn(Function):
     def forward(ctx, x, weight, bias):
         gran = ops.k_granule(x.dtype)
         xp = _pad_cols(x.contiguous(), gran)
-        w = _wmat(weight, x.dtype, xp.shape[1])
+        w, wt = _weights(weight, x.dtype, xp.shape[1])
         ctx.save_for_backward(xp, weight)
         ctx.has_bias = bias is not None
         ctx.cin = x.shape[1]
-        ctx.w = w   # the cast copy serves the backward too (one cast per step, not two)
+        ctx.w, ctx.wt = w, wt   # the cast copy serves the backward too (one cast per step, not two)
         return ops.gemm(xp, w, bias=None if bias is None else bias.detach().float().contiguous())
 
     @staticmethod
@@ -48,7 +60,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             # dx = dy W : the same GEMM with the transposed weight (cin, cout); cout padded to the K granule
             dyp = _pad_cols(dy, gran)
-            wt = _pad_cols(ctx.w[:, :ctx.cin].t().contiguous(), gran)
+            wt = ctx.wt if ctx.wt is not None else _pad_cols(ctx.w[:, :ctx.cin].t().contiguous(), gran)
             dx = ops.gemm(dyp, wt)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm_tn(dy, xp)[:, :ctx.cin].to(weight.dtype)
@@ -66,7 +78,7 @@ class SubMConvFn(Function):
         gran = ops.k_granule(x.dtype)
         xp = _pad_cols(x.contiguous(), gran)
         kvol = nbr.shape[1]
-        w = _wmat(weight, x.dtype, xp.shape[1])
+        w, ctx.wt = _weights(weight, x.dtype, xp.shape[1])
         ctx.save_for_backward(xp, weight, nbr, row_order)
         ctx.has_bias = bias is not None
         ctx.cin = x.shape[1]
@@ -85,10 +97,12 @@ class SubMConvFn(Function):
             # neighbour maps of a submanifold conv are symmetric: nbr[i][t] = j  <=>  nbr[j][kvol-1-t] = i, so
             # dx[j] = sum_t dy[nbr[j][t]] . W[:, kvol-1-t, :]  -- the forward kernel on mirrored, transposed taps
             dyp = _pad_cols(dy, gran)
-            w = weight.detach().reshape(cout, kvol, cin).flip(1).permute(2, 1, 0)  # (cin, kvol, cout)
-            if dyp.shape[1] != cout:
-                w = torch.nn.functional.pad(w, (0, dyp.shape[1] - cout))
-            wt = w.reshape(cin, -1).to(dy.dtype).contiguous()
+            wt = ctx.wt
+            if wt is None:
+                w = weight.detach().reshape(cout, kvol, cin).flip(1).permute(2, 1, 0)  # (cin, kvol, cout)
+                if dyp.shape[1] != cout:
+                    w = torch.nn.functional.pad(w, (0, dyp.shape[1] - cout))
+                wt = w.reshape(cin, -1).to(dy.dtype).contiguous()
             dx = ops.gemm(dyp, wt, nbr=nbr, kvol=kvol, row_order=row_order)
         if ctx.needs_input_grad[1]:
             dw = ops.gemm_tn(dy, xp, nbr, kvol).view(cout, kvol, xp.shape[1])[:, :, :cin]
@@ -268,9 +282,12 @@ def _lin_fwd(x, w, b):
     return ops.gemm(x, w, bias=None if b is None else b.detach().float().contiguous())
 
 
-def _lin_bwd(dy, x, w_cast, gran):
-    """-> dx, dW (fp32, (cout, cin)), db (fp32) of y = x w^T + b; w_cast (cout, cin) in the activation dtype."""
-    dx = ops.gemm(_pad_cols(dy, gran), _pad_cols(w_cast.t().contiguous(), gran))
+def _lin_bwd(dy, x, w_pair, gran):
+    """-> dx, dW (fp32, (cout, cin)), db (fp32) of y = x w^T + b; w_pair = _weights(...) of the layer."""
+    w_cast, wt = w_pair
+    if wt is None:
+        wt = _pad_cols(w_cast.t().contiguous(), gran)
+    dx = ops.gemm(_pad_cols(dy, gran), wt)
     return dx, ops.gemm_tn(dy, x), ops.col_reduce(dy)
 
 
@@ -293,21 +310,21 @@ class BlockFn(Function):
         xin = feat if same else conv_feat.contiguous()
         kvol = nbr.shape[1]
         f32 = lambda t: t.detach().float().contiguous()  # noqa: E731
-        w_conv = _wmat(conv_w, dt)
-        w_lin, w_qkv, w_proj = _wmat(lin_w, dt), _wmat(qkv_w, dt), _wmat(proj_w, dt)
-        w_fc1, w_fc2 = _wmat(fc1_w, dt), _wmat(fc2_w, dt)
-        c1 = ops.gemm(xin, w_conv, bias=f32(conv_b), nbr=nbr, kvol=kvol, row_order=row_order)
-        c2 = _lin_fwd(c1, w_lin, lin_b)
+        w_conv = _weights(conv_w, dt)
+        w_lin, w_qkv, w_proj = _weights(lin_w, dt), _weights(qkv_w, dt), _weights(proj_w, dt)
+        w_fc1, w_fc2 = _weights(fc1_w, dt), _weights(fc2_w, dt)
+        c1 = ops.gemm(xin, w_conv[0], bias=f32(conv_b), nbr=nbr, kvol=kvol, row_order=row_order)
+        c2 = _lin_fwd(c1, w_lin[0], lin_b)
         f1 = ops.layernorm(c2, f32(ln0_g), f32(ln0_b), eps, res=feat)
         t3 = ops.layernorm(f1, f32(n1_g), f32(n1_b), eps)
-        qkv = _lin_fwd(t3, w_qkv, qkv_b)
+        qkv = _lin_fwd(t3, w_qkv[0], qkv_b)
         a = ops.window_attention(qkv, wo, wi, heads, patch, scale)
-        p = _lin_fwd(a, w_proj, proj_b)
+        p = _lin_fwd(a, w_proj[0], proj_b)
         f2 = f1 + (p if mask1 is None else p * mask1)
         t5 = ops.layernorm(f2, f32(n2_g), f32(n2_b), eps)
-        h0 = _lin_fwd(t5, w_fc1, fc1_b)
+        h0 = _lin_fwd(t5, w_fc1[0], fc1_b)
         h = ops.affine_act(h0, None, None, ops.ACT_GELU)
-        m = _lin_fwd(h, w_fc2, fc2_b)
+        m = _lin_fwd(h, w_fc2[0], fc2_b)
         out = f2 + (m if mask2 is None else m * mask2)
         ctx.save_for_backward(xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2,
                               conv_w, ln0_g, n1_g, n2_g)
@@ -345,7 +362,9 @@ class BlockFn(Function):
         dc1, dW_lin, db_lin = _lin_bwd(dc2, c1, w_lin, gran)
         kvol = nbr.shape[1]
         cout, cin = conv_w.shape[0], conv_w.shape[-1]
-        wt = w_conv.view(cout, kvol, cin).flip(1).permute(2, 1, 0).reshape(cin, -1).contiguous()
+        wt = w_conv[1]
+        if wt is None:
+            wt = w_conv[0].view(cout, kvol, cin).flip(1).permute(2, 1, 0).reshape(cin, -1).contiguous()
         dxin = ops.gemm(_pad_cols(dc1, gran), wt, nbr=nbr, kvol=kvol, row_order=row_order)
         dW_conv = ops.gemm_tn(dc1, xin, nbr, kvol).view(conv_w.shape)
         db_conv = ops.col_reduce(dc1)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "ptv3_adamw_entry_bytes": (c_size_t, []),
     "ptv3_adamw_chunk": (c_int, []),
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
+    "ptv3_adamw_fill_shadow": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P]),
     "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P]),
     "ptv3_grid_hash": (c_int, [P, c_int64, c_double, c_int, P, P, P, P]),

@@ -13,11 +13,37 @@ from .lib import lib
 from .ops import _stream
 
 
+def _shadow_of(p, dtype):
+    """(natural, transposed) compute-dtype copies of a >= 2-d weight, created on first use.  Linear (out, in) ->
+    (in, out); SubMConv3d (out, k, k, k, in) -> (in, taps mirrored, out).  Kept on the Parameter together with the
+    torch version counter they were made at: any torch-side in-place change of the weight invalidates them, the
+    fused optimizer step (which writes them itself) does not."""
+    rows, cols = p.shape[0], p.shape[-1]
+    kvol = p.numel() // (rows * cols)
+    with torch.no_grad():
+        w = p.detach().reshape(rows, kvol, cols)
+        nat = w.reshape(rows, kvol * cols).to(dtype).contiguous()
+        tr = w.flip(1).permute(2, 1, 0).reshape(cols, kvol * rows).to(dtype).contiguous()
+    return {"version": p._version, "dtype": dtype, "nat": nat, "t": tr, "dims": (rows, cols, kvol)}
+
+
+def weight_shadow(p, dtype):
+    """The valid shadow of `p` in `dtype`, or None (no fused optimizer attached / stale)."""
+    sh = getattr(p, "_ptv3_shadow", None)
+    if sh is None or sh["dtype"] != dtype or sh["version"] != p._version:
+        return None
+    return sh
+
+
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, shadow_dtype=None):
+        """shadow_dtype (torch.bfloat16 / torch.float32 / None): keep compute-dtype and transposed copies of every
+        weight matrix up to date inside the step kernel (ptv3_adamw_fill_shadow); the training Functions of
+        ptv3_hip.autograd pick them up instead of casting / transposing the fp32 masters every step."""
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) > 8:
             raise ValueError("FusedAdamW: at most 8 parameter groups")
+        self.shadow_dtype = shadow_dtype
         self._key = None
         self._table = None
         self._nt = self._nb = 0
@@ -43,9 +69,19 @@ class FusedAdamW(torch.optim.Optimizer):
                 out.append((p, st, gi))
         return out
 
+    def _shadow(self, p):
+        if self.shadow_dtype is None or p.dim() < 2 or p.shape[-1] % 8 or p.shape[0] % 8:
+            return None
+        sh = weight_shadow(p, self.shadow_dtype)
+        if sh is None:
+            sh = p._ptv3_shadow = _shadow_of(p, self.shadow_dtype)
+        return sh
+
     def _build(self):
         ent = self._entries()
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), gi) for p, _, gi in ent)
+        shadows = [self._shadow(p) for p, _, _ in ent]
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), gi, 0 if sh is None else sh["nat"].data_ptr())
+                    for (p, _, gi), sh in zip(ent, shadows))
         if key == self._key:
             return
         esz, chunk = lib.ptv3_adamw_entry_bytes(), lib.ptv3_adamw_chunk()
@@ -56,6 +92,12 @@ class FusedAdamW(torch.optim.Optimizer):
             lib.check(lib.ptv3_adamw_fill_entry(base + i * esz, p.data_ptr(), p.grad.data_ptr(),
                                                 st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi,
                                                 blocks), "ptv3_adamw_fill_entry")
+            sh = shadows[i]
+            if sh is not None:
+                rows, cols, kvol = sh["dims"]
+                lib.check(lib.ptv3_adamw_fill_shadow(base + i * esz, sh["nat"].data_ptr(), sh["t"].data_ptr(), rows,
+                                                     cols, kvol, 0 if self.shadow_dtype == torch.float32 else 1),
+                          "ptv3_adamw_fill_shadow")
             blocks += (p.numel() + chunk - 1) // chunk
         dev = ent[0][0].device if ent else torch.device("cuda")
         self._table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)

@@ -175,3 +175,43 @@ def test_v3m2_train_step_vs_oracle_autograd(dev):
     gmax = max(v.abs().max().item() for v in ref.values())
     worst = max(((n, _rel(p.grad, ref[n], 1e-3 * gmax)) for n, p in model.named_parameters()), key=lambda t: t[1])
     assert worst[1] < 2e-3, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_shadow_weights_match_cast_path(dev, dtype):
+    """FusedAdamW(shadow_dtype=...) keeps compute-dtype and transposed / tap-mirrored copies of every weight inside its
+    step kernel; the training Functions read them instead of casting per step.  Same numbers as the cast path."""
+    import ptv3_scenes as S
+    from ptv3_hip.optim import FusedAdamW, weight_shadow
+    cfg = dict(TINY_CFG, drop_path=0.0)
+    torch.manual_seed(1234)
+    ma = _build(cfg, hidden_dim=32).to(dev).train()
+    mb = copy.deepcopy(ma)
+    for m in (ma, mb):
+        m.backbone.compute_dtype = dtype
+    data = {k: v.to(dev) for k, v in S.make_batch([1300, 900], in_channels=4, extent=96, seed=3, with_target=6).items()}
+    oa = FusedAdamW(ma.parameters(), lr=3e-3, weight_decay=0.01)
+    ob = FusedAdamW(mb.parameters(), lr=3e-3, weight_decay=0.01, shadow_dtype=dtype)
+    for step in range(3):
+        losses = []
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad()
+            torch.manual_seed(5)
+            out = m(data)
+            out["loss"].backward()
+            o.step()
+            losses.append(out["loss"].item())
+        assert losses[0] == losses[1], (step, losses)
+    for (n, p), q in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.equal(p, q), n
+    w = mb.backbone.enc.enc1.block0.cpe[0].weight          # a sparse-conv weight (out, 3, 3, 3, in)
+    sh = weight_shadow(w, dtype)
+    assert sh is not None
+    assert torch.equal(sh["nat"], w.detach().reshape(w.shape[0], -1).to(dtype))
+    ref_t = w.detach().reshape(w.shape[0], 27, w.shape[-1]).flip(1).permute(2, 1, 0).reshape(w.shape[-1], -1).to(dtype)
+    assert torch.equal(sh["t"], ref_t)
+    lin = mb.head[0].weight
+    assert torch.equal(weight_shadow(lin, dtype)["t"], lin.detach().t().to(dtype))
+    with torch.no_grad():
+        lin.mul_(2.0)                                       # a torch-side change invalidates the shadow
+    assert weight_shadow(lin, dtype) is None
