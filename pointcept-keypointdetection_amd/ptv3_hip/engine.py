@@ -245,22 +245,41 @@ def forward(backbone, point, dtype, head=None):
     batch = point.batch if derive_batch else point.batch.long().contiguous()
     nb = int(offset.shape[0])   # scene offsets and the coordinate maximum are read back by the executor on its
     dev = feat.device           # geometry stream: no synchronisation of the caller's stream here
-    code = torch.empty((k, n), dtype=torch.int64, device=dev)
-    order = torch.empty_like(code)
-    inverse = torch.empty_like(code)
-    if overlap:
+    resident = bool(getattr(backbone, "inputs_resident", False))
+    if resident:
+        # Everything the executor's own streams WRITE must come from memory torch's caching allocator will not hand
+        # out again behind their back: the allocator only orders re-use within the caller's stream, while the geometry
+        # (and, with overlap_calls, the feature) pipeline runs ahead of that stream.  A fresh torch.empty() here could
+        # be a block that still has caller-stream work pending on it (e.g. the sigmoid temporary of the previous
+        # call's head, queued behind that call's completion wait) - which would then scribble over this call's
+        # codes / orders while the geometry kernels are reading them.  Hence a persistent ring of three generations
+        # per shape: call i's tensors stay valid until call i+3 is issued.
         ring = backbone.__dict__.setdefault("_engine_out_ring", {})
-        rkey = (n, desc.dec_channels[0], dtype, desc.head_out if head is not None else 0, dev)
+        rkey = (n, k, desc.dec_channels[0], dtype, desc.head_out if head is not None else 0, dev)
         slot = ring.get(rkey)
-        if slot is None:   # three generations: call i's outputs stay valid until call i+3 is issued
-            slot = ring[rkey] = {"i": 0, "bufs": [
-                (torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev),
-                 torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None)
-                for _ in range(3)]}
-            torch.cuda.current_stream().synchronize()
-        out_feat, out_head = slot["bufs"][slot["i"] % 3]
+        if slot is None:
+            def gen():
+                return dict(code=torch.empty((k, n), dtype=torch.int64, device=dev),
+                            order=torch.empty((k, n), dtype=torch.int64, device=dev),
+                            inverse=torch.empty((k, n), dtype=torch.int64, device=dev),
+                            batch=torch.empty(n, dtype=torch.int64, device=dev),
+                            out_feat=torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev),
+                            out_head=(torch.empty((n, desc.head_out), dtype=torch.float32, device=dev)
+                                      if head is not None else None))
+            torch.cuda.synchronize(dev)        # nothing pending anywhere on the blocks these allocations receive
+            slot = ring[rkey] = {"i": 0, "bufs": [gen() for _ in range(3)]}
+            torch.cuda.synchronize(dev)
+        cur = slot["bufs"][slot["i"] % 3]
         slot["i"] += 1
+        code, order, inverse = cur["code"], cur["order"], cur["inverse"]
+        out_feat, out_head = cur["out_feat"], cur["out_head"]
+        if derive_batch:
+            batch = cur["batch"]
+            point["batch"] = batch
     else:
+        code = torch.empty((k, n), dtype=torch.int64, device=dev)
+        order = torch.empty_like(code)
+        inverse = torch.empty_like(code)
         out_feat = torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev)
         out_head = torch.empty((n, desc.head_out), dtype=torch.float32, device=dev) if head is not None else None
     # grow-only arena with a FIXED internal layout (arena_n / arena_b): earlier calls may still be executing out of
