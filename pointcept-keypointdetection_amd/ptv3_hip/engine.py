@@ -276,6 +276,14 @@ def forward(backbone, point, dtype, head=None):
         if derive_batch:
             batch = cur["batch"]
             point["batch"] = batch
+        # inputs that had to be converted just now were produced on the caller's stream, which the executor's
+        # streams do not wait for in these modes: settle them, and keep them alive for the ring generation
+        converted = [t for t, src in ((gc, point.grid_coord), (offset, point.offset)) if t is not src]
+        if not derive_batch and batch is not point.batch:
+            converted.append(batch)
+        if converted:
+            torch.cuda.current_stream().synchronize()
+        cur["keep"] = (gc, offset, batch, raw)
     else:
         code = torch.empty((k, n), dtype=torch.int64, device=dev)
         order = torch.empty_like(code)
