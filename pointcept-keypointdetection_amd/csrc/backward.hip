@@ -77,14 +77,15 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging units: 64 rows x 16 four-channel groups per operand = 4 units per thread
+  // staging: each thread owns a 4-row x 4-channel patch of both operands (rows 4*rg .. +3, channels 4*cg .. +3),
+  // transposes it in registers and stores 4 x (4 consecutive rows of one channel) = four 8/16-byte LDS stores per
+  // operand instead of sixteen element stores
+  const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
   V4 ra[4], rb[4];
   auto fetch = [&](int64_t rblk) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int unit = threadIdx.x + 256 * u;
-      const int row = unit >> 4, cg = unit & 15;
-      const int64_t r = rblk + row;
+      const int64_t r = rblk + 4 * rg + u;
       ra[u] = zero4<T>();
       rb[u] = zero4<T>();
       if (r < r1) {
@@ -97,16 +98,17 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   };
   fetch(r0);
   for (int64_t rblk = r0; rblk < r1; rblk += TN_RB) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int unit = threadIdx.x + 256 * u;
-      const int row = unit >> 4, cg = unit & 15;
-      const T* ea = reinterpret_cast<const T*>(&ra[u]);
-      const T* eb = reinterpret_cast<const T*>(&rb[u]);
+    {
+      const T* ea[4] = {reinterpret_cast<const T*>(&ra[0]), reinterpret_cast<const T*>(&ra[1]),
+                        reinterpret_cast<const T*>(&ra[2]), reinterpret_cast<const T*>(&ra[3])};
+      const T* eb[4] = {reinterpret_cast<const T*>(&rb[0]), reinterpret_cast<const T*>(&rb[1]),
+                        reinterpret_cast<const T*>(&rb[2]), reinterpret_cast<const T*>(&rb[3])};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        sA[(4 * cg + e) * TN_LS + row] = ea[e];
-        sB[(4 * cg + e) * TN_LS + row] = eb[e];
+        T ta[4] = {ea[0][e], ea[1][e], ea[2][e], ea[3][e]};
+        T tb[4] = {eb[0][e], eb[1][e], eb[2][e], eb[3][e]};
+        *reinterpret_cast<V4*>(sA + (4 * cg + e) * TN_LS + 4 * rg) = *reinterpret_cast<const V4*>(ta);
+        *reinterpret_cast<V4*>(sB + (4 * cg + e) * TN_LS + 4 * rg) = *reinterpret_cast<const V4*>(tb);
       }
     }
     __syncthreads();
