@@ -215,3 +215,27 @@ def test_shadow_weights_match_cast_path(dev, dtype):
     with torch.no_grad():
         lin.mul_(2.0)                                       # a torch-side change invalidates the shadow
     assert weight_shadow(lin, dtype) is None
+
+
+def test_train_step_vs_reference_golden(dev, golden_dir):
+    """The reference's own training-mode forward + torch-autograd backward (tests/golden/ptv3_tiny_train.npz, made by
+    importing the reference in place) reproduced by the HIP training path: loss, all gradients, running statistics."""
+    import numpy as np
+    import os
+    g = np.load(os.path.join(golden_dir, "ptv3_tiny_train.npz"))
+    cfg = dict(TINY_CFG, drop_path=0.0)
+    model = _build(cfg, hidden_dim=32)
+    model.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}, strict=True)
+    model = model.to(dev).train()
+    data = {k[3:]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith("in_")}
+    torch.manual_seed(int(g["shuffle_seed"]))
+    out = model(data)
+    out["loss"].backward()
+    assert abs(out["loss"].item() - float(g["loss"])) < 1e-4
+    gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("grad_"))
+    worst = max(((n, _rel(p.grad, torch.from_numpy(g["grad_" + n]), 1e-3 * gmax)) for n, p in model.named_parameters()),
+                key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst
+    for n, b in model.named_buffers():
+        if "running" in n:
+            assert _rel(b, torch.from_numpy(g["buf_" + n])) < 1e-4, n

@@ -162,3 +162,26 @@ def test_v3m2_oracle_matches_reference(golden_dir):
         assert orc.trace[name].shape == ref.shape, name
         assert (orc.trace[name] - ref).abs().max().item() < 1e-5, name
     assert (P["feat"] - torch.from_numpy(g["feat"])).abs().max().item() < 1e-5
+
+
+def test_training_oracle_matches_reference_autograd(golden_dir):
+    """Training semantics of the oracle (batch-statistic BatchNorm, running-stat momenta, loss) pinned to the
+    reference's own training-mode run + torch autograd (tests/golden/ptv3_tiny_train.npz)."""
+    from oracle import ptv3 as O
+    from make_golden_cfg import TINY_CFG
+    g = np.load(os.path.join(golden_dir, "ptv3_tiny_train.npz"))
+    cfg = dict(TINY_CFG, drop_path=0.0)
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
+    data = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    orc = O.OffsetKeypointOracle(cfg, sd, training=True)
+    torch.manual_seed(int(g["shuffle_seed"]))
+    out = orc.forward(data)
+    out["loss"].backward()
+    assert abs(out["loss"].item() - float(g["loss"])) < 1e-6
+    gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("grad_"))
+    for name, p in orc.named_parameters():
+        ref = torch.from_numpy(g["grad_" + name])
+        err = (p.grad - ref).abs().max().item()
+        assert err <= 1e-5 * max(ref.abs().max().item(), 1e-3 * gmax), (name, err)
+    for name, b in orc.named_buffers():
+        assert (b - torch.from_numpy(g["buf_" + name])).abs().max().item() < 1e-6, name
