@@ -260,7 +260,7 @@ template <> struct RowSum<float> {
 // from the window's voxel coordinates and the head's table column, both resident in LDS.
 struct RpeTable { const int32_t* grid; const float* table; int pos_bnd; };
 
-template <typename T, int ND, int RPE>
+template <typename T, int ND, int RPE, int QT>
 __global__ void __launch_bounds__(512)
 window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
                         const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
@@ -268,7 +268,6 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
                         RpeTable rt) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
-  constexpr int QT = WaCfg<T, ND>::QT;
   constexpr int KS = D + 4;
   constexpr bool SUM_MFMA = RowSum<T>::kOnMfma;
   const int VS = Kpad + WaFull<T>::VPAD;
@@ -501,6 +500,76 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   }
 }
 
+
+// ---- launch configuration of the resident-window kernel.
+// A wave walks all key tiles of its QT query tiles serially, so the pair (waves per workgroup, QT) trades
+// per-wave serial length (deep levels: few windows, the launch lasts as long as ONE wave) against redundant
+// staging of the window (every workgroup of a (window, head) pair stages all of K/V) and against the number of
+// rounds the grid needs (LDS bounds the workgroups resident per CU).  full_config() evaluates a small cost model
+// (cycles on the busiest CU) over the candidates; PTV3_ATTN_WAVES / PTV3_ATTN_QT force a choice for experiments.
+template <typename T> struct FullArgs {
+  const T* qkv; const int32_t* wo; const int32_t* wi; T* out; int C, H, K, Kpad, nwin; float scale_log2e;
+  const float* rpe; RpeTable rt; int waves; size_t lds; hipStream_t s;
+};
+
+template <typename T, int ND, int RPE, int QT>
+static void launch_full(const FullArgs<T>& a) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, RPE, QT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  const int QB = a.waves * QT * 16;
+  const int qsplit = (a.K + QB - 1) / QB;
+  const unsigned nwg = (unsigned)a.nwin * a.H * qsplit;
+  hipLaunchKernelGGL((window_attn_full_kernel<T, ND, RPE, QT>), dim3(nwg), dim3(a.waves * 64), a.lds, a.s, a.qkv, a.wo,
+                     a.wi, a.out, a.C, a.H, a.K, a.Kpad, a.nwin, qsplit, a.scale_log2e, a.rpe, a.rt);
+}
+
+template <typename T, int ND, int QT>
+static void launch_full_rpe(const FullArgs<T>& a, int rpe_mode) {
+  if (rpe_mode == 2) launch_full<T, ND, 2, QT>(a);
+  else if (rpe_mode == 1) launch_full<T, ND, 1, QT>(a);
+  else launch_full<T, ND, 0, QT>(a);
+}
+
+static void full_config(int64_t pairs, int K, int qt_max, size_t lds, int* waves_out, int* qt_out) {
+  const char* ew = getenv("PTV3_ATTN_WAVES");
+  const char* eq = getenv("PTV3_ATTN_QT");
+  const int fw = ew ? atoi(ew) : 0, fq = eq ? atoi(eq) : 0;
+  const int cap_lds = (int)std::max<size_t>(1, (160 * 1024) / lds);
+  const double tiles = (K + WA_KT - 1) / WA_KT;
+  double best = 1e300;
+  int bw = 8, bq = qt_max;
+  for (int waves = 8; waves >= 4; waves >>= 1) {
+    if (fw && waves != fw) continue;
+    for (int qt = qt_max; qt >= 1; qt >>= 1) {
+      if (fq && qt != fq) continue;
+      const int cap = std::min(cap_lds, 32 / waves);  // workgroups resident per CU (LDS, wave slots)
+      const int QB = waves * qt * 16;
+      const int64_t nwg = pairs * ((K + QB - 1) / QB);
+      const int64_t per_round = 256LL * cap;
+      const int64_t full_rounds = nwg / per_round;
+      const int64_t rest = nwg - full_rounds * per_round;
+      // one round with b workgroups on the busiest CU: staging (latency-bound, shared by the b workgroups only
+      // partly) + the serial walk of a wave, stretched by the waves sharing its SIMD
+      auto round_cost = [&](int64_t b) {
+        const double wps = std::max(1.0, (double)b * waves / 4.0);           // waves per SIMD
+        const double eff = wps >= 4 ? 0.70 : (wps >= 2 ? 0.50 : 0.35);        // issue efficiency seen in profiles
+        const double walk = tiles * qt * 244.0 * wps / eff;                    // cycles
+        const double stage = 2500.0 + 4.0 * K * (8.0 / waves) * std::max<double>(1.0, (double)b * 0.5);
+        return walk + stage;
+      };
+      double cost = full_rounds * round_cost(cap);
+      if (rest) cost += round_cost((rest + 255) / 256);
+      if (cost < best) { best = cost; bw = waves; bq = qt; }
+    }
+  }
+  *waves_out = bw;
+  *qt_out = bq;
+}
+
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
                               int K, int nwin, float scale, const float* rpe, hipStream_t s,
@@ -514,42 +583,16 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
     set_error("window_attn_rpe: window of %d keys does not fit the resident-window kernel", K);
     return PTV3_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
   if (lds_full <= 160 * 1024) {
-    // queries per workgroup: 8 waves (512 queries at head_dim 16) when there are plenty of windows, fewer
-    // waves per workgroup when the grid would otherwise leave CUs idle
-    static int min_waves = 0;
-    if (!min_waves) {
-      const char* e = getenv("PTV3_ATTN_MIN_WAVES");
-      min_waves = e ? atoi(e) : 4;
-      if (min_waves != 1 && min_waves != 2 && min_waves != 4 && min_waves != 8) min_waves = 4;
-    }
-    int waves = 8;
-    while (waves > min_waves && (int64_t)nwin * H * ((K + waves * QT * 16 - 1) / (waves * QT * 16)) < 512) waves >>= 1;
-    const int QB = waves * QT * 16;
-    const int qsplit = (K + QB - 1) / QB;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, 0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, 1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, 2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set = true;
-    }
-    const unsigned nwg = (unsigned)nwin * H * qsplit;
-    if (rt.table)
-      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, 2>), dim3(nwg), dim3(waves * 64), lds_full, s,
-                         (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
-                         scale * 1.44269504088896340736f, rpe, rt);
-    else if (rpe)
-      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, 1>), dim3(nwg), dim3(waves * 64), lds_full, s,
-                         (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
-                         scale * 1.44269504088896340736f, rpe, rt);
-    else
-      hipLaunchKernelGGL((window_attn_full_kernel<T, ND, 0>), dim3(nwg), dim3(waves * 64), lds_full, s,
-                         (const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, qsplit,
-                         scale * 1.44269504088896340736f, rpe, rt);
+    int waves, qt;
+    full_config(nwin * (int64_t)H, K, WaCfg<T, ND>::QT, lds_full, &waves, &qt);
+    const FullArgs<T> a{(const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, scale * 1.44269504088896340736f, rpe,
+                        rt, waves, lds_full, s};
+    const int rpe_mode = rt.table ? 2 : (rpe ? 1 : 0);
+    constexpr int QTMAX = WaCfg<T, ND>::QT;
+    if (qt >= 4 && QTMAX >= 4) launch_full_rpe<T, ND, (QTMAX >= 4 ? 4 : QTMAX)>(a, rpe_mode);
+    else if (qt >= 2 && QTMAX >= 2) launch_full_rpe<T, ND, (QTMAX >= 2 ? 2 : QTMAX)>(a, rpe_mode);
+    else launch_full_rpe<T, ND, 1>(a, rpe_mode);
     PTV3_LAUNCH_CHECK();
     return PTV3_OK;
   }
