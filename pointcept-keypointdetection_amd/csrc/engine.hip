@@ -13,6 +13,7 @@
 // Block :318-338, SerializedPooling :371-444, SerializedUnpooling :471-482 in eval mode.
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -540,6 +541,10 @@ extern "C" size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int6
 
 extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
                             const ptv3_forward_io* io, void* workspace, size_t workspace_bytes, void* stream) {
+  // the executor's streams, events, call parity and arena halves are process-wide: calls from several host threads
+  // take turns (they still overlap on the GPU exactly as consecutive calls of one thread do)
+  static std::mutex g_forward_mutex;
+  std::lock_guard<std::mutex> guard(g_forward_mutex);
   if (int r = check_desc(desc)) return r;
   PTV3_REQUIRE(io->n >= 1 && io->b >= 1, "forward: empty batch");
   PTV3_REQUIRE(io->depth <= 16, "forward: depth %d > 16", io->depth);
