@@ -305,13 +305,16 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
     for (int j = tid; j < 3 * rpe_num; j += nthreads) sTab[j] = rt.table[(int64_t)j * H + h] * 1.44269504088896340736f;
   }
 
-  // ---- stage the whole window: K row-major, V transposed
+  // ---- stage the whole window: K row-major, V transposed.  All gathers of a pass are issued before the first LDS
+  // write; a 1024-key window at head_dim 16 is ONE pass of 8 loads per thread for an 8-wave workgroup (the gathers
+  // are latency-bound: two dependent passes cost two round trips)
   constexpr int CH = D / 4;
   const int total = Kpad * CH;
-  for (int e0 = tid; e0 < total; e0 += 4 * nthreads) {
-    V4 rk[4], rv[4];
+  auto stage_pass = [&](const int e0, auto unroll_tag) {
+    constexpr int U = decltype(unroll_tag)::value;
+    V4 rk[U], rv[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nthreads;
       rk[u] = zero4<T>();
       rv[u] = zero4<T>();
@@ -325,7 +328,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const int e = e0 + u * nthreads;
       if (e < total) {
         const int kk = e / CH, ch = e % CH;
@@ -335,6 +338,11 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
         for (int q = 0; q < 4; ++q) sV[(size_t)(4 * ch + q) * VS + kk] = pv[q];
       }
     }
+  };
+  {
+    int e0 = tid;
+    for (; e0 + 4 * nthreads < total; e0 += 8 * nthreads) stage_pass(e0, std::integral_constant<int, 8>{});
+    for (; e0 < total; e0 += 4 * nthreads) stage_pass(e0, std::integral_constant<int, 4>{});
   }
 
   // ---- Q fragments of this wave (global loads overlap the staging above)
