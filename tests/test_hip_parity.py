@@ -131,6 +131,35 @@ def test_window_attention_golden_fp32(dev, golden_dir, case):
     assert (proj.cpu() - torch.from_numpy(c["out"])).abs().max().item() < FP32_TOL
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_attention_launch_configs_bitwise(dev, dtype):
+    """Every (waves per workgroup, query tiles per wave) launch configuration of the resident-window kernel gives the
+    bits of the configuration the cost model picks: a query's key walk does not depend on how queries are dealt to
+    waves.  Shapes: ragged scenes (borrowed rows), a partial last key tile, head_dim 16 and 32."""
+    import os
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(11)
+    for sizes, c, h, patch in (([1500, 1100], 64, 4, 1024), ([900], 32, 2, 200), ([2600], 64, 2, 512)):
+        n = sum(sizes)
+        qkv = torch.randn(n, 3 * c, generator=g).to(dev).to(dtype)
+        off = torch.tensor(sizes).cumsum(0)
+        order = torch.cat([torch.randperm(m, generator=g) + (int(off[i]) - m) for i, m in enumerate(sizes)])
+        inverse = torch.empty_like(order)
+        inverse[order] = torch.arange(n)
+        wo, wi = ops.window_plan(order[None].to(dev), inverse[None].to(dev), off.to(dev), off.tolist(), patch)
+        wo, wi = wo[0].contiguous(), wi[0].contiguous()
+        try:
+            ref = ops.window_attention(qkv, wo, wi, h, patch, (c // h) ** -0.5)
+            for waves in (8, 4):
+                for qt in (4, 2, 1):
+                    os.environ["PTV3_ATTN_WAVES"], os.environ["PTV3_ATTN_QT"] = str(waves), str(qt)
+                    out = ops.window_attention(qkv, wo, wi, h, patch, (c // h) ** -0.5)
+                    assert torch.equal(out, ref), (sizes, c, h, patch, waves, qt)
+        finally:
+            os.environ.pop("PTV3_ATTN_WAVES", None)
+            os.environ.pop("PTV3_ATTN_QT", None)
+
+
 def test_window_attention_bf16(dev, golden_dir):
     from ptv3_hip import ops
     c = _attn_case(_g(golden_dir, "attention.npz"), 2, dev)
