@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 from ptv3_hip import ops
 from pointcept.models.builder import MODELS, build_model
-from pointcept.models.utils.hip_layers import Linear, BatchNorm1d, ReLU, _no_training
+from pointcept.models.utils.hip_layers import Linear, BatchNorm1d, ReLU, _no_training, check_sync_batchnorm
 
 
 @MODELS.register_module()
@@ -33,6 +33,7 @@ class OffsetKeypointPTv3(nn.Module):
         self.cls_criterion = nn.BCEWithLogitsLoss(reduction="none")
 
     def forward(self, data_dict):
+        check_sync_batchnorm(self)
         point_output = self.backbone(data_dict, _head=None if self.training else self.head)
         if "_head_out" in point_output.keys():   # head ran inside the native executor
             pred_flat = point_output.pop("_head_out")

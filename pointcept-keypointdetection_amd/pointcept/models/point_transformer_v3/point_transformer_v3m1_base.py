@@ -23,7 +23,8 @@ from pointcept.models.builder import MODELS
 from pointcept.models.utils.misc import offset2bincount  # noqa: F401  (reference import surface)
 from pointcept.models.utils.structure import Point
 from pointcept.models.utils.sparse import SubMConv3d, _ParamCache
-from pointcept.models.utils.hip_layers import (Linear, LayerNorm, BatchNorm1d, GELU, DropPath, _no_training)
+from pointcept.models.utils.hip_layers import (Linear, LayerNorm, BatchNorm1d, GELU, DropPath, _no_training,
+                                                check_sync_batchnorm)
 from pointcept.models.modules import PointModule, PointSequential
 
 
@@ -666,6 +667,7 @@ class PointTransformerV3(PointModule):
         return torch.float32
 
     def forward(self, data_dict, _head=None):
+        check_sync_batchnorm(self)  # sync_bn=True: torch converted the BatchNorm1d modules, take them back
         # eval: no autograd tape (fused kernels / native executor); train: one taped Function per layer
         with torch.set_grad_enabled(self.training and torch.is_grad_enabled()):
             use_engine = not self.training and self.use_engine and _engine.eligible(self, _head)

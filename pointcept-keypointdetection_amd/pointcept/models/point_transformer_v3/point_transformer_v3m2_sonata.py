@@ -20,7 +20,7 @@ from ptv3_hip import autograd as A
 from pointcept.models.builder import MODELS
 from pointcept.models.utils.structure import Point
 from pointcept.models.utils.sparse import SubMConv3d
-from pointcept.models.utils.hip_layers import Linear, LayerNorm, GELU, DropPath
+from pointcept.models.utils.hip_layers import Linear, LayerNorm, GELU, DropPath, check_sync_batchnorm
 from pointcept.models.modules import PointModule, PointSequential
 from .point_transformer_v3m1_base import RPE, SerializedAttention, MLP  # noqa: F401  (same classes, same kernels)
 
@@ -320,6 +320,7 @@ class PointTransformerV3(PointModule):
         return torch.float32
 
     def forward(self, data_dict):
+        check_sync_batchnorm(self)
         with torch.set_grad_enabled(self.training and torch.is_grad_enabled()):
             point = Point(data_dict)
             feat = point.feat

@@ -104,6 +104,34 @@ class BatchNorm1d(nn.BatchNorm1d):
         return ops.affine_act(x, s, t, act)
 
 
+def adopt_sync_batchnorm(root):
+    """`tools/train.py` with `sync_bn=True` runs `nn.SyncBatchNorm.convert_sync_batchnorm(model)` (engines/train.py:
+    256-257), which replaces every BatchNorm1d of this package by torch's SyncBatchNorm.  Put the HIP BatchNorm1d back -
+    around the SAME Parameter / buffer objects, so optimizer, DistributedDataParallel and state_dict keep their
+    references - flagged with the process group: its taped Function then all-reduces the batch statistics
+    (ptv3_hip/autograd.py BatchNormActFn).  Called by the model wrappers on their first forward and on every training
+    forward; returns the number of modules adopted."""
+    count = 0
+    for parent in list(root.modules()):
+        for name, child in list(parent._modules.items()):
+            if isinstance(child, nn.SyncBatchNorm):
+                bn = BatchNorm1d(child.num_features, eps=child.eps, momentum=child.momentum, affine=child.affine,
+                                 track_running_stats=child.track_running_stats)
+                bn._parameters, bn._buffers = child._parameters, child._buffers
+                bn.sync_group = child.process_group if child.process_group is not None else True
+                bn.train(child.training)
+                parent._modules[name] = bn
+                count += 1
+    return count
+
+
+def check_sync_batchnorm(model):
+    """cheap guard for the model wrappers: walk the tree on the first forward and on training forwards only"""
+    if model.training or not model.__dict__.get("_sync_bn_checked", False):
+        adopt_sync_batchnorm(model)
+        model.__dict__["_sync_bn_checked"] = True
+
+
 class GELU(nn.GELU):
     def forward(self, x):
         if self.training:

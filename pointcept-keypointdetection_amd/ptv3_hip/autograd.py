@@ -129,18 +129,36 @@ class LayerNormFn(Function):
         return dx, dg.to(ctx.pdtype), db.to(ctx.pdtype), None
 
 
+def _all_reduce(t, group):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 class BatchNormActFn(Function):
     """act(BatchNorm1d(x)) with batch statistics (training) or running statistics (eval)
     (:439-442, 508-511; offset_keypoint_ptv3.py head).  Running buffers are updated in place like torch
-    (momentum, unbiased variance)."""
+    (momentum, unbiased variance).  `sync` (a process group, or True for the default one) makes the statistics those
+    of the batch over ALL ranks, as torch.nn.SyncBatchNorm does after engines/train.py:256-257 converted the model:
+    column sums and the row count are all-reduced in forward, the two gradient sums in backward; weight / bias
+    gradients stay local sums (DistributedDataParallel averages them)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act, sync=None):
         x = x.contiguous()
         m = x.shape[0]
+        group = None if sync is True else sync
+        ctx.sync, ctx.group = bool(sync) and training, group
         if training:
-            mean = ops.col_reduce(x) / m
-            var = ops.col_reduce(x, mu=mean.contiguous(), mode=3)[1] / m  # centred second pass (biased variance)
+            if ctx.sync:
+                head = torch.cat([ops.col_reduce(x).reshape(-1), x.new_full((1,), float(m), dtype=torch.float32)])
+                head = _all_reduce(head, group)
+                m = int(round(head[-1].item()))
+                mean = head[:-1] / m
+                var = _all_reduce(ops.col_reduce(x, mu=mean.contiguous(), mode=3)[1].contiguous(), group) / m
+            else:
+                mean = ops.col_reduce(x) / m
+                var = ops.col_reduce(x, mu=mean.contiguous(), mode=3)[1] / m  # centred second pass (biased variance)
             if running_mean is not None:
                 with torch.no_grad():
                     running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
@@ -153,28 +171,29 @@ class BatchNormActFn(Function):
         scale = (gamma * rstd).contiguous()
         shift = (bias.detach().float() - mean * scale).contiguous()
         ctx.save_for_backward(x, scale, shift, mean.contiguous(), rstd.contiguous(), gamma)
-        ctx.training, ctx.act, ctx.pdtype = training, act, weight.dtype
+        ctx.training, ctx.act, ctx.pdtype, ctx.count = training, act, weight.dtype, m
         return ops.affine_act(x, scale, shift, act)
 
     @staticmethod
     def backward(ctx, dy):
         x, scale, shift, mean, rstd, gamma = ctx.saved_tensors
         dy = dy.contiguous()
-        m = x.shape[0]
+        m = ctx.count
         dpre = ops.act_bwd(dy, x, ctx.act, scale, shift) if ctx.act != ops.ACT_NONE else dy
         sums = ops.col_reduce(dpre, x, mean, rstd, mode=2)  # sum dpre, sum dpre * xhat
         dbeta, dgamma = sums[0], sums[1]
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.training:
-                k1, k2 = sums[0] / m, sums[1] / m
+                tot = _all_reduce(sums.clone(), ctx.group) if ctx.sync else sums
+                k1, k2 = tot[0] / m, tot[1] / m
                 ca = gamma * rstd
                 cb = -ca * rstd * k2
                 cc = ca * (mean * rstd * k2 - k1)
             else:
                 ca, cb, cc = scale, torch.zeros_like(scale), torch.zeros_like(scale)
             dx = ops.affine2(dpre, x, ca.contiguous(), cb.contiguous(), cc.contiguous())
-        return dx, dgamma.to(ctx.pdtype), dbeta.to(ctx.pdtype), None, None, None, None, None, None
+        return dx, dgamma.to(ctx.pdtype), dbeta.to(ctx.pdtype), None, None, None, None, None, None, None
 
 
 class ActFn(Function):
@@ -254,8 +273,13 @@ def layer_norm(x, weight, bias, eps):
 
 
 def batch_norm_act(x, bn, act=ops.ACT_NONE):
+    sync = getattr(bn, "sync_group", None)
+    if sync is not None:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(None if sync is True else sync) > 1):
+            sync = None
     return BatchNormActFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training,
-                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, act)
+                                bn.momentum if bn.momentum is not None else 0.1, bn.eps, act, sync)
 
 
 def activation(x, act):

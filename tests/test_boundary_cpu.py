@@ -115,3 +115,20 @@ def test_point_dict_surface():
     assert q["extra"] == 5 and q.pop("extra") == 5
     with pytest.raises(AttributeError):
         q.missing
+
+
+def test_sync_batchnorm_conversion_is_taken_back():
+    """sync_bn=True (engines/train.py:256-257): torch replaces BatchNorm1d by SyncBatchNorm; the package adopts the
+    converted modules back around the same tensors (optimizer / DDP / state_dict references stay valid)."""
+    import torch
+    from pointcept.models.utils.hip_layers import BatchNorm1d, adopt_sync_batchnorm
+    seq = torch.nn.Sequential(torch.nn.Linear(4, 8), BatchNorm1d(8, eps=1e-3, momentum=0.01))
+    keys = list(seq.state_dict().keys())
+    seq = torch.nn.SyncBatchNorm.convert_sync_batchnorm(seq)
+    assert isinstance(seq[1], torch.nn.SyncBatchNorm)
+    params, bufs = list(seq.parameters()), list(seq.buffers())
+    assert adopt_sync_batchnorm(seq) == 1 and adopt_sync_batchnorm(seq) == 0
+    assert isinstance(seq[1], BatchNorm1d) and seq[1].sync_group is True
+    assert seq[1].eps == 1e-3 and seq[1].momentum == 0.01
+    assert all(a is b for a, b in zip(params, seq.parameters())) and all(a is b for a, b in zip(bufs, seq.buffers()))
+    assert list(seq.state_dict().keys()) == keys

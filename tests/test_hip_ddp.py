@@ -71,3 +71,63 @@ def test_ddp_two_ranks_average_gradients(tmp_path):
         got = torch.load(os.path.join(str(tmp_path), f"g{r}.pt"), weights_only=True)
         for g, e in zip(got, ref):
             assert (g - e.cpu()).abs().max().item() <= 1e-6 + 1e-5 * e.abs().max().item()
+
+
+# ---------------------------------------------------------------- sync_bn=True (engines/train.py:256-257)
+def _bn_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _paths()
+    from pointcept.models.utils.hip_layers import BatchNorm1d, adopt_sync_batchnorm
+    from ptv3_hip import ops
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(3)
+    seq = torch.nn.Sequential(BatchNorm1d(48, eps=1e-3, momentum=0.01)).to(dev).train()
+    with torch.no_grad():
+        seq[0].weight.copy_(torch.linspace(0.5, 1.5, 48))
+        seq[0].bias.copy_(torch.linspace(-0.5, 0.5, 48))
+    seq = torch.nn.SyncBatchNorm.convert_sync_batchnorm(seq)      # what tools/train.py does
+    assert isinstance(seq[0], torch.nn.SyncBatchNorm)
+    params = list(seq.parameters())
+    assert adopt_sync_batchnorm(seq) == 1 and isinstance(seq[0], BatchNorm1d)
+    assert all(a is b for a, b in zip(params, seq.parameters()))   # same Parameter objects
+    g = torch.Generator().manual_seed(100)
+    full = torch.randn(700 + 500, 48, generator=g) * 2 + 1
+    w = torch.randn(700 + 500, 48, generator=g)
+    lo, hi = (0, 700) if rank == 0 else (700, 1200)                # ragged split of one global batch
+    x = full[lo:hi].to(dev).requires_grad_(True)
+    y = seq[0](x, act=ops.ACT_GELU)
+    (y * w[lo:hi].to(dev)).sum().backward()
+    torch.save(dict(y=y.detach().cpu(), dx=x.grad.cpu(), dw=seq[0].weight.grad.cpu(), db=seq[0].bias.grad.cpu(),
+                    rm=seq[0].running_mean.cpu(), rv=seq[0].running_var.cpu()), os.path.join(out_dir, f"bn{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_match_one_global_batch(tmp_path):
+    """BatchNorm statistics over ALL ranks: two ranks holding 700 / 500 rows of one batch reproduce torch's BatchNorm1d
+    + GELU on the whole batch (output, input gradient, running statistics); weight / bias gradients are the local
+    sums whose total is the single-process gradient."""
+    assert torch.cuda.is_available()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_bn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    torch.manual_seed(3)
+    bn = torch.nn.BatchNorm1d(48, eps=1e-3, momentum=0.01).train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, 48))
+        bn.bias.copy_(torch.linspace(-0.5, 0.5, 48))
+    g = torch.Generator().manual_seed(100)
+    full = (torch.randn(1200, 48, generator=g) * 2 + 1).requires_grad_(True)
+    w = torch.randn(1200, 48, generator=g)
+    y = torch.nn.functional.gelu(bn(full))
+    (y * w).sum().backward()
+    r = [torch.load(os.path.join(str(tmp_path), f"bn{k}.pt"), weights_only=True) for k in range(2)]
+    close = lambda a, b, tol=2e-5: (a - b).abs().max().item() <= tol * (1 + b.abs().max().item())  # noqa: E731
+    assert close(torch.cat([r[0]["y"], r[1]["y"]]), y.detach())
+    assert close(torch.cat([r[0]["dx"], r[1]["dx"]]), full.grad)
+    assert close(r[0]["dw"] + r[1]["dw"], bn.weight.grad, 1e-4) and close(r[0]["db"] + r[1]["db"], bn.bias.grad, 1e-4)
+    for k in range(2):
+        assert close(r[k]["rm"], bn.running_mean) and close(r[k]["rv"], bn.running_var)
