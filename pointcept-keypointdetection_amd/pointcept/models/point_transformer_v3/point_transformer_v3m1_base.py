@@ -136,6 +136,9 @@ class SerializedAttention(PointModule):
                 return out
             bias = self.rpe(self.get_rel_pos(point, wo.long()))
         if self.training:
+            p_drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else float(self.attn_drop)
+            if p_drop > 0.0:  # the reference drops attention probabilities (:203, :211); no such kernel here yet
+                raise NotImplementedError("SerializedAttention: attn_drop > 0 has no training kernel on the HIP path")
             return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale)
         return ops.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, rpe_bias=bias)
 
