@@ -204,7 +204,7 @@ def test_window_attention_rpe(dev, golden_dir):
 # implicit GEMM: linear and sparse conv
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,cin,cout", [(1, 4, 4), (67, 32, 96), (1000, 64, 19), (513, 128, 512), (4099, 512, 24),
-                                         (300, 36, 64)])
+                                         (300, 36, 64), (9001, 128, 320), (8300, 256, 72)])
 def test_linear_fp32(dev, m, cin, cout):
     from ptv3_hip import ops
     g = torch.Generator().manual_seed(m + cin)
@@ -225,10 +225,11 @@ def test_linear_fp32(dev, m, cin, cout):
     assert (o2.cpu() - (pre + res[ridx.long()])).abs().max().item() < FP32_TOL
 
 
-def test_linear_bf16(dev):
+@pytest.mark.parametrize("m", [777, 9001])
+def test_linear_bf16(dev, m):
     from ptv3_hip import ops
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(777, 128, generator=g)
+    x = torch.randn(m, 128, generator=g)
     w = torch.randn(96, 128, generator=g) / 128 ** 0.5
     b = torch.randn(96, generator=g)
     ref = torch.nn.functional.linear(x.bfloat16().float(), w.bfloat16().float(), b)
