@@ -1,22 +1,36 @@
 """Headline benchmark: PTv3 (fork config) + keypoint-offset head forward, Mpoints/s.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
 One step = one eval forward of OffsetKeypointPTv3 (configs/my_dataset/offset_keypoint_ptv3.py shape,
 46.2 M parameters, 1024-point windows) over one synthetic scene batch already resident in HBM.
 Scenes are independent, so N GPUs run N replicas on their own scenes (weak scaling, no data-path
 collective); value = total points / max-over-ranks time.
-Prints ONE JSON line on rank 0 with `roofline` (dominant matrix-core kernel family, HIP-event timed
-inside the timed region) and, at N = 1, `cpu_baseline` (the oracle on the host cores, bounded sample).
+
+Launch: under `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) every process is one
+rank.  Without them, `--gpus N` with N > 1 starts N child processes ITSELF before anything touches the GPU - one
+process per GPU, `init_process_group("nccl")` over tcp://127.0.0.1:<free port>, the process model of the
+reference's pointcept/engines/launch.py:36-113 - and returns their exit code.
+
+Prints ONE JSON line on rank 0 with
+  value / ms_per_step     K forwards in the timed region (two in flight, see config.forwards_in_flight)
+  latency_ms_median       SURVEY 8(d)'s metric: median of >= 20 single forwards, each bracketed by synchronize
+  fp32                    the same two figures in fp32 (exact-fp32 MFMA), the arithmetic of the 1e-4 parity bar
+  parity                  fp32 AND bf16 outputs of the HIP path vs the oracle on the cpu_baseline scene
+  roofline                dominant kernel family, HIP-event timed on the launch stream
+  cpu_baseline            the oracle on the host cores (N = 1 only, bounded sample)
+  other_workloads         BASELINE configs[2]: PTv3 semseg (enable_flash=True) on a 120k-point LiDAR-like scan
 """
 import argparse
 import json
 import os
+import socket
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "pointcept-keypointdetection_amd"), os.path.join(ROOT, "tests", "golden")):
+for p in (ROOT, os.path.join(ROOT, "pointcept-keypointdetection_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -25,6 +39,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 PEAK_HBM = 8000.0                       # GB/s, same table (6.3 TB/s is the measured achievable copy rate)
+GRAD_BYTES = 46181592 * 4               # fp32 gradient of OffsetKeypointPTv3 (backbone 46,158,272 + head 23,320)
 
 
 def rank_scene_seeds(rank, scenes_per_rank):
@@ -33,12 +48,31 @@ def rank_scene_seeds(rank, scenes_per_rank):
 
 
 def reduce_over_ranks(value, device, op):
-    """MAX of the timed region / SUM of the points over the job (the only collectives of the bench)."""
+    """MAX of the timed region / SUM of the points over the job (the only collectives of the forward bench)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=op)
     return float(t.item())
+
+
+def allreduce_probe(device, nbytes, reps=5):
+    """Timed all-reduce of one fp32 buffer the size of the model's gradient: the collective a DDP
+    step issues.  bus GB/s = 2 (n-1)/n x bytes / time (the rccl-tests convention)."""
+    world = dist.get_world_size()
+    buf = torch.ones(nbytes // 4, dtype=torch.float32, device=device)
+    sync = torch.cuda.synchronize if device.type == "cuda" else (lambda: None)
+    dist.all_reduce(buf)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    dt = reduce_over_ranks(dt, device, dist.ReduceOp.MAX)
+    return {"bytes": nbytes, "ms": round(dt * 1e3, 3), "algbw_GBps": round(nbytes / dt / 1e9, 2),
+            "busbw_GBps": round(2 * (world - 1) / world * nbytes / dt / 1e9, 2), "ranks": world}
 
 
 def pmc_traffic(args, kernel_family):
@@ -78,7 +112,7 @@ def pmc_sq():
             "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)", **out} if out else None
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -87,30 +121,95 @@ def parse():
     ap.add_argument("--scenes", type=int, default=1, help="scenes per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--kind", default="surface", choices=["surface", "lidar"])
+    ap.add_argument("--model", default="offset", choices=["offset", "semseg"],
+                    help="offset = OffsetKeypointPTv3 over the fork config (headline); semseg = DefaultSegmentorV2 "
+                         "(19 classes) over the upstream PTv3 semseg backbone (enable_flash=True), BASELINE configs[2]")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the fp32 line and the configs[2] workload")
     ap.add_argument("--no-overlap", action="store_true",
                     help="forward mode: do not let consecutive forwards overlap (one feature pipeline in flight)")
     ap.add_argument("--mode", default="forward", choices=["forward", "train"],
                     help="forward = the headline metric (default); train = forward + backward + fused AdamW per "
                          "step, DistributedDataParallel over RCCL when --gpus > 1 (BASELINE configs[3] shape)")
-    return ap.parse_args()
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU work: exercise launch, rendezvous (gloo), sharding and reductions only; the JSON "
+                         "line then carries value null and rehearsal true (never a reported number)")
+    return ap.parse_args(argv)
 
 
-def build_model(device):
-    from pointcept.models import build_model
-    from make_golden_cfg import FORK_CFG
-    torch.manual_seed(1234)
-    model = build_model(dict(type="OffsetKeypointPTv3", num_keypoints=6,
-                             backbone_conf=dict(type="PT-v3m1", **FORK_CFG))).eval()
+# --------------------------------------------------------------------------------------------------
+# launch: one process per GPU (pointcept/engines/launch.py:36-113)
+# --------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rank_entry(local_rank, world, port, argv):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run(parse(argv))
+
+
+def self_launch(args, argv):
+    """Start args.gpus fresh processes (spawn: new interpreters, nothing inherited from a GPU context - this parent
+    never initialises the GPU) and wait for them.  Rank 0 prints the JSON line on the shared stdout."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_entry, args=(r, args.gpus, port, argv)) for r in range(args.gpus)]
+    for p in procs:
+        p.start()
+    code = 0
+    for p in procs:
+        p.join()
+        code = code or (p.exitcode or 0)
+    if code:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    return code
+
+
+# --------------------------------------------------------------------------------------------------
+# models and scenes
+# --------------------------------------------------------------------------------------------------
+def perturb_bn(model):
     gen = torch.Generator().manual_seed(99)
     for n, b in model.named_buffers():  # non-trivial eval BatchNorm statistics
         if n.endswith("running_mean"):
             b.copy_(torch.randn(b.shape, generator=gen) * 0.1)
         if n.endswith("running_var"):
             b.copy_(torch.rand(b.shape, generator=gen) + 0.5)
+
+
+def build_model(device, kind="offset"):
+    from pointcept.models import build_model
+    from ptv3_hip.configs import FORK_CFG, SEMSEG_CFG
+    torch.manual_seed(1234)
+    if kind == "semseg":
+        cfg = SEMSEG_CFG
+        model = build_model(dict(type="DefaultSegmentorV2", num_classes=19, backbone_out_channels=64,
+                                 backbone=dict(type="PT-v3m1", **cfg))).eval()
+    else:
+        cfg = FORK_CFG
+        model = build_model(dict(type="OffsetKeypointPTv3", num_keypoints=6,
+                                 backbone_conf=dict(type="PT-v3m1", **cfg))).eval()
+    perturb_bn(model)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    return model.to(device), sd, FORK_CFG
+    return model.to(device), sd, cfg
+
+
+def make_scene(points, kind, seed):
+    """surface: dense synthetic surface scan (pools ~4x per stage); lidar: 64-ring scan at its natural 0.05 m voxel
+    size in a 2048^3 grid (serialization depth 11, pools ~1.3x per stage) - the SemanticKITTI-like shape."""
+    import ptv3_scenes as S
+    return S.make_scene(points, 4, None if kind == "surface" else 2048, seed, kind)
 
 
 def host_cores():
@@ -126,7 +225,8 @@ def host_cores():
 
 
 def cpu_baseline(sd, cfg, model, device, n_points):
-    """Oracle (CPU restatement of the reference path) on the host cores + parity of the HIP fp32 path."""
+    """Oracle (CPU restatement of the reference path) on the host cores + parity of the HIP path - in fp32 (the
+    1e-4 bar) AND in bf16 (the arithmetic `value` is measured in) - on the same scene."""
     from oracle import ptv3 as O
     import ptv3_scenes as S
     cores = host_cores()
@@ -138,18 +238,87 @@ def cpu_baseline(sd, cfg, model, device, n_points):
     with torch.no_grad():
         ref = orc.forward(data)
     dt = time.perf_counter() - t0
-    model.backbone.compute_dtype = torch.float32
-    torch.manual_seed(11)
-    with torch.no_grad():
-        out = model({k: v.to(device) for k, v in data.items()})
-    pred = out["pred"].float().cpu()
-    l2 = (pred[..., :3] - ref["pred"][..., :3]).norm(dim=-1).max().item()
-    lg = (pred[..., 3] - ref["pred"][..., 3]).abs().max().item()
+    parity = {"tolerance_fp32": 1e-4, "sample_points": n_points,
+              "reference": "oracle (torch-CPU fp32 restatement, pinned to the reference by tests/golden)",
+              "logit_scale": round(ref["logits"].abs().max().item(), 4)}
+    datad = {k: v.to(device) for k, v in data.items()}
+    for name, dt_ in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        model.backbone.compute_dtype = dt_
+        torch.manual_seed(11)
+        with torch.no_grad():
+            out = model(datad)
+        pred = out["pred"].float().cpu()
+        d3 = (pred[..., :3] - ref["pred"][..., :3]).norm(dim=-1)
+        dm = (pred[..., 3] - ref["pred"][..., 3]).abs()
+        parity[name] = {"offset_l2_max": d3.max().item(), "offset_l2_mean": d3.mean().item(),
+                        "mask_prob_abs_max": dm.max().item(), "mask_prob_abs_mean": dm.mean().item()}
     return ({"value": round(n_points / dt / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
              "sample": f"oracle (torch-CPU fp32 restatement) forward of one {n_points}-point surface scene, "
-                       f"{dt:.1f} s wall, {cores} threads"},
-            {"offset_l2_max": l2, "mask_prob_abs_max": lg, "tolerance": 1e-4, "sample_points": n_points,
-             "mode": "fp32"})
+                       f"{dt:.1f} s wall, {cores} threads"}, parity)
+
+
+# --------------------------------------------------------------------------------------------------
+# timing helpers
+# --------------------------------------------------------------------------------------------------
+def timed_steps(step, steps, warmup, world, device):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return reduce_over_ranks(time.perf_counter() - t0, device, dist.ReduceOp.MAX)
+
+
+def latency_median(step, iters):
+    """median wall time of single forwards, torch.cuda.synchronize() on both sides of each."""
+    ts = []
+    torch.cuda.synchronize()
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return statistics.median(ts)
+
+
+def forward_figures(model, batch, key, args, world, device, overlap):
+    """(elapsed of K steps in throughput mode, median single-forward latency in ms)"""
+    def step():
+        with torch.no_grad():
+            return model(batch)[key]
+    model.backbone.overlap_calls = overlap
+    elapsed = timed_steps(step, args.steps, args.warmup, world, device)
+    model.backbone.overlap_calls = False
+    step()
+    lat = latency_median(step, max(20, args.steps))
+    return elapsed, lat, step
+
+
+def semseg_lidar_workload(device, args, world):
+    """BASELINE configs[2] beside the headline: PTv3 semseg forward on one 120k-point LiDAR-like scan."""
+    import ptv3_scenes as S
+    model, _, _ = build_model(device, "semseg")
+    model.backbone.compute_dtype = torch.bfloat16
+    model.backbone.inputs_resident = True
+    batch = {k: v.to(device) for k, v in S.collate([make_scene(120000, "lidar", 1000)]).items()}
+    elapsed, lat, step = forward_figures(model, batch, "seg_logits", args, world, device, True)
+    with torch.no_grad():
+        pts = model(batch, return_point=True)["point"]["_stage_points"]
+    torch.cuda.synchronize()
+    return {"workload": "DefaultSegmentorV2 (19 classes) over PT-v3m1 (fork widths, enable_flash=True, patch 1024), "
+                        "1 x 120000-point LiDAR-like scan, 2048^3 grid (depth 11), bf16",
+            "value": round(120000 * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms_median": round(lat, 3),
+            "stage_points": pts}
 
 
 def train_bench(args, model, device, world, rank, local_rank):
@@ -169,33 +338,21 @@ def train_bench(args, model, device, world, rank, local_rank):
     groups = [dict(params=[p for n, p in model.named_parameters() if "block" in n], lr=2e-4),
               dict(params=[p for n, p in model.named_parameters() if "block" not in n])]
     opt = FusedAdamW(groups, lr=2e-3, weight_decay=5e-3, shadow_dtype=dtype)
-    scenes = [S.make_scene(args.points, 4, None, seed, args.kind) for seed in rank_scene_seeds(rank, args.scenes)]
+    scenes = [make_scene(args.points, args.kind, seed) for seed in rank_scene_seeds(rank, args.scenes)]
     batch = {k: v.to(device) for k, v in S.collate(scenes, with_target=6).items()}
     n_points = args.points * args.scenes
+    last = {}
 
     def step():
         opt.zero_grad()
         out = net(batch)
         out["loss"].backward()
         opt.step()
-        return out["loss"]
+        last["loss"] = out["loss"]
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = reduce_over_ranks(elapsed, device, dist.ReduceOp.MAX)
+    elapsed = timed_steps(step, args.steps, args.warmup, world, device)
     total_points = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
+    probe = allreduce_probe(device, GRAD_BYTES) if world > 1 else None
     if rank == 0:
         print(json.dumps({
             "metric": "Mpoints/sec PTv3 train step (fwd+bwd+AdamW) @100k pts/scene, 1024-pt window",
@@ -207,18 +364,44 @@ def train_bench(args, model, device, world, rank, local_rank):
                                    f"{args.scenes} x {args.points}-point synthetic {args.kind} scene(s) per GPU, "
                                    f"patch 1024, drop_path 0.3, fused AdamW (2 param groups)",
                        "points_per_gpu": n_points,
-                       "parallelism": f"dp{world} (DDP over RCCL, 184.7 MB fp32 gradient all-reduce)" if world > 1
-                       else "dp1"},
-            "roofline": None, "cpu_baseline": None, "final_loss": float(loss.item())}), flush=True)
+                       "parallelism": f"dp{world} (DDP over RCCL, {GRAD_BYTES / 1e6:.1f} MB fp32 gradient all-reduce)"
+                       if world > 1 else "dp1"},
+            "rccl_ranks": world, "allreduce_probe": probe,
+            "roofline": None, "cpu_baseline": None, "final_loss": float(last["loss"].item())}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def main():
-    args = parse()
+def rehearse(args, world, rank):
+    """--rehearse-launch: everything around the GPU work (used by the CPU tests of the N > 1 path)."""
+    import ptv3_scenes as S
+    device = torch.device("cpu")
+    seeds = rank_scene_seeds(rank, args.scenes)
+    scenes = [S.make_scene(min(args.points, 2000), 4, 64, s) for s in seeds]
+    n_points = int(S.collate(scenes)["offset"][-1])
+    if world > 1:
+        dist.barrier()
+    elapsed = reduce_over_ranks(1.0 + rank, device, dist.ReduceOp.MAX)
+    total = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
+    seen = int(reduce_over_ranks(1, device, dist.ReduceOp.SUM))
+    probe = allreduce_probe(device, 1 << 20, reps=2) if world > 1 else None
+    if rank == 0:
+        print(json.dumps({"metric": "launch rehearsal (no GPU work)", "value": None, "rehearsal": True,
+                          "n_gpus": world, "rccl_ranks": seen, "elapsed_max": elapsed, "total_points": total,
+                          "scene_seeds_rank0": seeds, "allreduce_probe": probe, "mode": args.mode}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.rehearse_launch:
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+        return rehearse(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the HIP path has no CPU fallback)"
     # one rank per GPU; PTV3_BENCH_BACKEND=gloo lets several ranks rehearse the multi-rank path on ONE GPU (RCCL
     # needs a device per rank) - used only to test this script, never for reported numbers
@@ -231,55 +414,38 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend=backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    seen = int(reduce_over_ranks(1, device, dist.ReduceOp.SUM))   # ranks that really joined the communicator
 
     import ptv3_scenes as S
     from ptv3_hip import ops
-    model, sd, cfg = build_model(device)
+    model, sd, cfg = build_model(device, args.model)
+    out_key = "pred" if args.model == "offset" else "seg_logits"
 
     cpu, parity = None, None
     if args.mode == "train":
         return train_bench(args, model, device, world, rank, dev_index)
-    if rank == 0 and world == 1 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0 and args.model == "offset":
         cpu, parity = cpu_baseline(sd, cfg, model, device, args.cpu_sample)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.backbone.compute_dtype = dtype
     model.backbone.inputs_resident = True  # the scene batch sits in HBM before the timed region (bench contract)
-    # throughput mode: two forwards in flight (the small deep levels of step i run under the chip-filling level-0
-    # kernels of step i+1); every step is still one complete forward of the scene and all of them finish inside
-    # the timed region (synchronize on both sides)
-    model.backbone.overlap_calls = not args.no_overlap
     # every rank owns its own scene(s): shard = scene, no exchange on the data path
-    scenes = [S.make_scene(args.points, 4, None, seed, args.kind) for seed in rank_scene_seeds(rank, args.scenes)]
+    scenes = [make_scene(args.points, args.kind, seed) for seed in rank_scene_seeds(rank, args.scenes)]
     batch = {k: v.to(device) for k, v in S.collate(scenes).items()}
     n_points = args.points * args.scenes
 
-    def step():
-        with torch.no_grad():
-            return model(batch)["pred"]
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # ---- timed region: K steps, nothing but the forward (barrier + synchronize on both sides)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    elapsed = reduce_over_ranks(elapsed, device, dist.ReduceOp.MAX)
+    # ---- timed region: K steps, nothing but the forward (barrier + synchronize on both sides).  Throughput mode:
+    # two forwards in flight (the small deep levels of step i run under the chip-filling level-0 kernels of step
+    # i+1); every step is still one complete forward of the scene and all of them finish inside the timed region.
+    # Then SURVEY 8(d)'s figure: the median of single, synchronize-bracketed forwards (one in flight).
+    elapsed, latency, step = forward_figures(model, batch, out_key, args, world, device, not args.no_overlap)
     total_points = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
 
     # ---- kernel durations: the SAME K steps again with HIP events on the launch stream around every
     # matrix-core launch.  Kept out of the timed region above because the ~340 event records per step are
     # queue markers that cost ~1.5 ms per step (measured: 5.0 ms vs 3.4 ms) - they would falsify `value`.
+    roofline = None
     if not args.no_kernel_events:
         # one forward in flight here: with two overlapped forwards an event bracket would time the kernel while it
         # shares the chip with the other forward's kernels; the roofline entry describes the kernel alone
@@ -288,10 +454,6 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-
-    # ---- per-kernel-family device time from the events recorded during the timed steps
-    roofline = None
-    if not args.no_kernel_events:
         fam = ops.profile_collect()
         ops.profile_enable(False)
         dom = max(fam, key=lambda k: fam[k]["ms"])
@@ -317,30 +479,60 @@ def main():
                     "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()},
                     "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()},
                     "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()}}
+        if rank == 0:
+            roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(args, roofline["kernel"])
+            if (args.points, args.scenes, args.dtype, args.kind, args.model) == (100000, 1, "bf16", "surface", "offset"):
+                roofline["pmc_sq"] = pmc_sq()
 
-    if roofline is not None and rank == 0:
-        roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(args, roofline["kernel"])
-        if (args.points, args.scenes, args.dtype, args.kind) == (100000, 1, "bf16", "surface"):
-            roofline["pmc_sq"] = pmc_sq()
+    # ---- the same workload in fp32 (the arithmetic of the 1e-4 parity bar), and BASELINE configs[2]
+    fp32, extra = None, None
+    default_run = world == 1 and not args.no_extra and args.model == "offset"
+    if default_run and args.dtype == "bf16":
+        model.backbone.compute_dtype = torch.float32
+        e32, l32, _ = forward_figures(model, batch, out_key, args, world, device, not args.no_overlap)
+        fp32 = {"value": round(n_points * args.steps / e32 / 1e6, 4), "unit": "Mpoints/s",
+                "ms_per_step": round(e32 / args.steps * 1e3, 3), "latency_ms_median": round(l32, 3)}
+        model.backbone.compute_dtype = dtype
+    if default_run and rank == 0:
+        del model, batch
+        torch.cuda.empty_cache()
+        extra = {"semseg_lidar_120k": semseg_lidar_workload(device, args, world)}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        name = ("OffsetKeypointPTv3 (PT-v3m1 fork config, 46.2M params)" if args.model == "offset" else
+                "DefaultSegmentorV2 (19 classes, PT-v3m1 fork widths, enable_flash=True)")
         line = {
             "metric": "Mpoints/sec PTv3 fwd @100k pts/scene, 1024-pt window; keypoint offset L2 vs ref",
             "value": round(total_points * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"OffsetKeypointPTv3 (PT-v3m1 fork config, 46.2M params) eval forward, "
+            "config": {"workload": f"{name} eval forward, "
                                    f"{args.scenes} x {args.points}-point synthetic {args.kind} scene(s) per GPU, "
                                    f"patch 1024, serialization + sparse conv + attention + head included",
                        "points_per_gpu": n_points, "parallelism": f"replicas x{world} (scene-sharded, no collective)",
                        "forwards_in_flight": 1 if args.no_overlap else 2},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+            "latency_ms_median": round(latency, 3),
+            "latency_mpoints_per_s": round(n_points / latency / 1e3, 4),
+            "rccl_ranks": seen,
+            "fp32": fp32,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": extra,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no external launcher: become one.  Nothing above this line touches the GPU.
+        return self_launch(args, argv)
+    run(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

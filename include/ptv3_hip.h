@@ -59,8 +59,12 @@ int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_bit, int64_t
 
 /* ---- patch partition ----------------------------------------------------------------------
  * replaces SerializedAttention.get_padding_and_inverse (point_transformer_v3m1_base.py:114-170).
- * offset: (b) int64 cumulative scene ends (device); patch = K.  n_pad = sum_b pad_to_K(n_b).
- * pad: (n_pad) int64, unpad: (n) int64, cu_seqlens: (n_pad/K + 1) int32. */
+ * offset: (b) int64 cumulative scene ends (device); patch = K.  A scene of n_b > K points is padded to a
+ * multiple of K (pad-by-borrowing, :144-154) and cut into K-slot windows; a scene of n_b <= K points stays
+ * ONE window of n_b slots (:131-133 - only reachable with enable_flash=True, where K is fixed; with
+ * enable_flash=False K = min(smallest scene, patch) and every window has K slots).
+ * n_pad = sum_b (n_b > K ? ceil_to_K(n_b) : n_b);  windows = sum_b ceil(n_b / K).
+ * pad: (n_pad) int64, unpad: (n) int64, cu_seqlens: (windows + 1) int32 window starts + n_pad. */
 int ptv3_pad_plan(const int64_t* offset, int b, int64_t n, int64_t n_pad, int patch, int64_t* pad,
                   int64_t* unpad, int32_t* cu_seqlens, void* stream);
 
@@ -71,10 +75,11 @@ int ptv3_window_maps(const int64_t* order, const int64_t* inverse, const int64_t
                      int32_t* win_inverse, void* stream);
 
 /* pad plan + both maps for all k orders in one launch (no pad / unpad materialised): the executor's form of
- * the two entry points above.  order / inverse: (k, n); win_order: (k, n_pad); win_inverse: (k, n). */
+ * the two entry points above.  order / inverse: (k, n); win_order: (k, n_pad); win_inverse: (k, n);
+ * cu_seqlens (optional, NULL = skip): (windows + 1) int32 as ptv3_pad_plan writes it. */
 int ptv3_window_plan(const int64_t* order, const int64_t* inverse, const int64_t* offset, int b, int k,
                      int64_t n, int64_t n_pad, int patch, int32_t* win_order, int32_t* win_inverse,
-                     void* stream);
+                     int32_t* cu_seqlens, void* stream);
 
 /* ---- window attention ----------------------------------------------------------------------
  * replaces the vanilla branch of SerializedAttention.forward (point_transformer_v3m1_base.py:188-216)
@@ -87,6 +92,20 @@ int ptv3_window_plan(const int64_t* order, const int64_t* inverse, const int64_t
 int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
                          void* out, int64_t n, int64_t n_pad, int c, int heads, int patch, float scale,
                          const float* rpe_bias, int dtype, void* stream);
+
+/* The enable_flash=True form of the same attention: what flash_attn_varlen_qkvpacked_func(qkv[order], cu_seqlens,
+ * max_seqlen=K, softmax_scale) computes at the reference's call site (point_transformer_v3m1_base.py:207-215;
+ * flash-attn 2.6.3 is a CUDA-only wheel outside the reference tree - its published semantics are restated:
+ * independent softmax(scale q k^T) v per sequence [cu_seqlens[w], cu_seqlens[w+1]) and head).  Windows may be
+ * ragged: window w holds the padded slots [cu_seqlens[w], cu_seqlens[w+1]), 1..max_seqlen of them (a scene with
+ * fewer than K points is one short window, :131-133).  cu_seqlens: (num_windows + 1) int32, device, as
+ * ptv3_pad_plan / ptv3_window_plan write it.  sum_len_sq (host, measurement only): sum over windows of len^2
+ * for the algorithmic flop count, 0 = unknown (n_pad * max_seqlen is used).  Arithmetic follows `dtype` like
+ * ptv3_window_attn_fwd (the reference casts qkv to bf16 for flash-attn whatever the model dtype, :209). */
+int ptv3_window_attn_varlen_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                const int32_t* cu_seqlens, int num_windows, void* out, int64_t n, int64_t n_pad,
+                                int c, int heads, int max_seqlen, float scale, double sum_len_sq, int dtype,
+                                void* stream);
 
 /* Same attention with the relative-position bias of RPE (point_transformer_v3m1_base.py:29-48 applied to
  * get_rel_pos :104-112) evaluated INSIDE the kernel: bias(q, k, h) = sum over the 3 axes of
@@ -277,7 +296,16 @@ typedef struct {
                                                 /* REQUIRED whenever calls may still be in flight (inputs_resident /    */
                                                 /* overlap_calls) and scene sizes vary: with 0 the parts are laid out   */
                                                 /* for THIS call's n and would move under the previous call's kernels.  */
+  void* executor;                               /* ptv3_executor_create() handle, or NULL = the current device's default */
+                                                /* executor.  An executor owns the internal streams / events / call     */
+                                                /* parity; calls on one executor are ordered as described above, calls  */
+                                                /* on different executors (other models, other devices) are independent. */
 } ptv3_forward_io;
+
+/* Executor handles (optional).  create() binds to the CURRENT device; destroy() drains the executor's streams.
+ * Every workspace handed to ptv3_forward with inputs_resident / overlap_calls must stay with ONE executor. */
+void* ptv3_executor_create(void);
+int ptv3_executor_destroy(void* executor);
 
 size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int64_t n, int b);  /* sized for overlap_calls too */
 int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
@@ -328,6 +356,11 @@ int ptv3_window_attn_bwd(const void* qkv, const void* out, const void* dout, con
                          const int32_t* win_inverse, void* dqkv, int64_t n, int64_t n_pad, int c, int heads,
                          int patch, float scale, int dtype, void* workspace, size_t workspace_bytes,
                          void* stream);
+/* backward of ptv3_window_attn_varlen_fwd (ragged windows; same workspace size) */
+int ptv3_window_attn_varlen_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                                const int32_t* win_inverse, const int32_t* cu_seqlens, int num_windows, void* dqkv,
+                                int64_t n, int64_t n_pad, int c, int heads, int max_seqlen, float scale, int dtype,
+                                void* workspace, size_t workspace_bytes, void* stream);
 /* fused multi-tensor AdamW (torch.optim.AdamW semantics; pointcept/utils/optimizer.py builds it with one
  * extra "block" parameter group): a device table of ptv3_adamw_entry_bytes()-sized entries, filled on the
  * host by ptv3_adamw_fill_entry; entry i owns blocks [first_block_i, first_block_i + ceil(numel_i / chunk)).
@@ -343,6 +376,10 @@ int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* grad, void*
  * cast or transpose weights between steps. */
 int ptv3_adamw_fill_shadow(void* entry_host, void* shadow, void* shadow_t, int rows, int cols, int kvol,
                            int shadow_dtype);
+/* optional, after ptv3_adamw_fill_entry: this tensor has taken `step_lag` steps fewer than the `step` argument of
+ * ptv3_adamw_step (torch.optim.AdamW keeps state["step"] per parameter: a parameter that first receives a gradient
+ * later, or a resumed checkpoint, engines/hooks/misc.py:269); its bias corrections use step - step_lag. */
+int ptv3_adamw_fill_step_lag(void* entry_host, int64_t step_lag);
 int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
                     const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
                     float grad_scale, void* stream);

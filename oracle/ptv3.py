@@ -1,7 +1,8 @@
 """Oracle (test infrastructure): plain torch-CPU fp32 restatement of the PTv3 forward.
 
 Functional (state_dict driven) so that it shares no code with the product modules.
-Follows, in eval mode, with enable_flash=False / upcast_*=False / enable_rpe optional:
+Follows, in eval mode, with upcast_*=False / enable_rpe optional; enable_flash=False (vanilla branch) or
+enable_flash=True (fixed K, ragged windows through varlen_attention()):
   * PointTransformerV3.forward           point_transformer_v3m1_base.py:699-714
   * Embedding                            :485-515   (SubMConv3d k=5 -> BN(eps 1e-3) -> GELU)
   * Block.forward                        :318-338   (xCPE, pre-norm attn, pre-norm MLP)
@@ -13,7 +14,9 @@ Follows, in eval mode, with enable_flash=False / upcast_*=False / enable_rpe opt
 Third-party arithmetic restated here (absent from /root/reference):
   * spconv 2.3.6 SubMConv3d  -> subm_conv3d()  [weight (O,k0,k1,k2,I); parity unpinned]
   * torch_scatter.segment_csr(max|mean) -> segment_reduce()
-Pinned by tests/golden/ptv3_*.npz (reference code run with these two stubs).
+  * flash-attn 2.6.3 flash_attn_varlen_qkvpacked_func -> varlen_attention()  [published semantics: exact
+    softmax(scale q k^T) v per sequence and head; parity unpinned against the CUDA wheel]
+Pinned by tests/golden/ptv3_*.npz (reference code run with these stubs).
 """
 import math
 import numpy as np
@@ -103,6 +106,48 @@ def window_attention(feat, qkv_w, qkv_b, proj_w, proj_b, order, inverse, pad, un
     return F.linear(out, proj_w, proj_b)
 
 
+def varlen_attention(qkv, cu_seqlens, H, scale, bf16_io=False):
+    """flash_attn.flash_attn_varlen_qkvpacked_func(qkv (T, 3, H, D), cu_seqlens, max_seqlen, softmax_scale) restated:
+    every sequence [cu[w], cu[w+1]) attends within itself, per head.  flash-attn 2.6.3 (uv_requirements.txt:36) is a
+    CUDA-only wheel outside the reference tree; this is its documented function, evaluated in fp32.
+    bf16_io=True adds what the call site itself does to the data (v3m1_base.py:209: qkv.to(torch.bfloat16)) and what
+    the library returns (its input dtype): inputs and output rounded to bf16."""
+    T = qkv.shape[0]
+    D = qkv.shape[-1]
+    x = qkv.reshape(T, 3, H, D)
+    if bf16_io:
+        x = x.to(torch.bfloat16)
+    x = x.float()
+    out = torch.empty(T, H, D, dtype=torch.float32)
+    cu = [int(v) for v in cu_seqlens]
+    lens = [b - a for a, b in zip(cu[:-1], cu[1:])]
+    # sequences of equal length are evaluated together (a scene's full windows); short ones one by one
+    by_len = {}
+    for w, ln in enumerate(lens):
+        by_len.setdefault(ln, []).append(cu[w])
+    for ln, starts in by_len.items():
+        idx = (torch.tensor(starts).unsqueeze(1) + torch.arange(ln).unsqueeze(0)).reshape(-1)
+        blk = x[idx].reshape(len(starts), ln, 3, H, D).permute(2, 0, 3, 1, 4)   # (3, W, H, ln, D)
+        attn = torch.softmax((blk[0] * scale) @ blk[1].transpose(-2, -1), dim=-1)
+        out[idx] = (attn @ blk[2]).transpose(1, 2).reshape(-1, H, D)
+    if bf16_io:
+        out = out.to(torch.bfloat16)
+    return out
+
+
+def window_attention_flash(feat, qkv_w, qkv_b, proj_w, proj_b, order, inverse, pad, unpad, cu_seqlens, H,
+                           bf16_io=False):
+    """SerializedAttention.forward, enable_flash=True branch (:172-222 with :207-215)."""
+    C = feat.shape[1]
+    scale = (C // H) ** -0.5
+    o = order[pad]
+    inv = unpad[inverse]
+    qkv = F.linear(feat, qkv_w, qkv_b)[o]
+    out = varlen_attention(qkv.reshape(-1, 3, H, C // H), cu_seqlens, H, scale, bf16_io).reshape(-1, C)
+    out = out.to(qkv.dtype)[inv]
+    return F.linear(out, proj_w, proj_b)
+
+
 def window_attention_core(qkv, order, inverse, pad, unpad, H, K):
     """Only the gather -> softmax(QK^T)V -> scatter part of :184-216 (what the HIP kernel fuses)."""
     C = qkv.shape[1] // 3
@@ -156,6 +201,8 @@ class PTv3Oracle:
         self.stride = c.get("stride", (2, 2, 2, 2))
         self.shuffle_orders = c.get("shuffle_orders", True)
         self.enable_rpe = c.get("enable_rpe", False)
+        self.enable_flash = c.get("enable_flash", True)   # constructor default of the reference (:549)
+        self.flash_bf16_io = False   # True: also apply the call site's bf16 cast of qkv / bf16 result (:209-214)
         self.enc_mode = c.get("enc_mode", False)
         self.num_stages = len(self.enc_depths)
         self.trace = {}
@@ -204,18 +251,25 @@ class PTv3Oracle:
         x = self._ln(feat, name + ".norm1.0")
         # attention (:172-222)
         offset = P["offset"].numpy()
-        K = sfc.patch_size_for(offset, patch_size)
+        # enable_flash=False: K shrinks to the smallest scene (:173-176); True: K is the configured patch
+        K = int(patch_size) if self.enable_flash else sfc.patch_size_for(offset, patch_size)
         key = ("pad", K)
         if key not in P:
             pad, unpad, cu = sfc.pad_plan(offset, K)
             P[key] = (torch.from_numpy(pad), torch.from_numpy(unpad), torch.from_numpy(cu))
-        pad, unpad, _ = P[key]
+        pad, unpad, cu = P[key]
         rpe = sd.get(name + ".attn.rpe.rpe_table") if self.enable_rpe else None
-        x = window_attention(x, sd[name + ".attn.qkv.weight"], sd[name + ".attn.qkv.bias"],
-                             sd[name + ".attn.proj.weight"], sd[name + ".attn.proj.bias"],
-                             P["serialized_order"][order_index], P["serialized_inverse"][order_index],
-                             pad, unpad, H, K, rpe_table=rpe, grid_coord=P["grid_coord"],
-                             patch_size_cfg=patch_size)
+        if self.enable_flash:
+            x = window_attention_flash(x, sd[name + ".attn.qkv.weight"], sd[name + ".attn.qkv.bias"],
+                                       sd[name + ".attn.proj.weight"], sd[name + ".attn.proj.bias"],
+                                       P["serialized_order"][order_index], P["serialized_inverse"][order_index],
+                                       pad, unpad, cu, H, bf16_io=self.flash_bf16_io)
+        else:
+            x = window_attention(x, sd[name + ".attn.qkv.weight"], sd[name + ".attn.qkv.bias"],
+                                 sd[name + ".attn.proj.weight"], sd[name + ".attn.proj.bias"],
+                                 P["serialized_order"][order_index], P["serialized_inverse"][order_index],
+                                 pad, unpad, H, K, rpe_table=rpe, grid_coord=P["grid_coord"],
+                                 patch_size_cfg=patch_size)
         if name + ".ls1.0.gamma" in sd:     # LayerScale of "PT-v3m2" (v3m2_sonata.py:26-38, 349)
             x = x * sd[name + ".ls1.0.gamma"]
         feat = shortcut + x
@@ -415,6 +469,33 @@ class OffsetKeypointOracle:
         final[..., 3] = torch.sigmoid(pred[..., 3])
         out["pred"] = final
         out["logits"] = pred
+        return out
+
+
+class SegmentorOracle:
+    """DefaultSegmentorV2 (pointcept/models/default.py:41-95) around "PT-v3m1" or "PT-v3m2": backbone -> (enc_mode:
+    concatenate the pooled levels back up, :70-75) -> seg_head Linear -> criteria.  Only CrossEntropyLoss
+    (models/losses/misc.py: nn.CrossEntropyLoss(ignore_index) * loss_weight) is restated for the loss value."""
+
+    def __init__(self, backbone_conf, state_dict, variant="PT-v3m1", ignore_index=-1, loss_weight=1.0):
+        cls = PTv3m2Oracle if variant == "PT-v3m2" else PTv3Oracle
+        self.backbone = cls(backbone_conf, state_dict, prefix="backbone.")
+        self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items() if k.startswith("seg_head.")}
+        self.ignore_index, self.loss_weight = ignore_index, loss_weight
+
+    def forward(self, data):
+        P = self.backbone.backbone(data)
+        while "pooling_parent" in P:
+            parent = P.pop("pooling_parent")
+            inverse = P.pop("pooling_inverse")
+            parent["feat"] = torch.cat([parent["feat"], P["feat"][inverse]], dim=-1)
+            P = parent
+        feat = P["feat"]
+        logits = F.linear(feat, self.sd["seg_head.weight"], self.sd["seg_head.bias"]) if self.sd else feat
+        out = {"seg_logits": logits}
+        if "segment" in data:
+            out["loss"] = F.cross_entropy(logits, data["segment"].long().cpu(),
+                                          ignore_index=self.ignore_index) * self.loss_weight
         return out
 
 

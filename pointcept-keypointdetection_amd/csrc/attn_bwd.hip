@@ -21,6 +21,7 @@ struct AttnBwdArgs {
   void* dqkv_pad; float* lse; float* delta;
   int c, heads, patch, nwin;
   float scale, scale_log2e;
+  const int32_t* cu;  // ragged windows (ptv3_window_attn_varlen_bwd): slots [cu[w], cu[w+1]) of window w, else NULL
 };
 
 template <int ND> struct AbCfg {
@@ -47,10 +48,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
   const int h = (blockIdx.x / qblocks) % a.heads;
   const int w = blockIdx.x / (qblocks * a.heads);
   const int c3 = 3 * a.c;
-  const int64_t slot0 = (int64_t)w * a.patch;
+  const int64_t slot0 = a.cu ? (int64_t)a.cu[w] : (int64_t)w * a.patch;
+  const int P = a.cu ? a.cu[w + 1] - a.cu[w] : a.patch;  // slots of this window
+  if (qb * 64 >= P) return;                               // workgroup-uniform
   const int jq = qb * 64 + wave * 16 + i;
-  const bool qv = jq < a.patch;
-  const int64_t pq = slot0 + (qv ? jq : a.patch - 1);
+  const bool qv = jq < P;
+  const int64_t pq = slot0 + (qv ? jq : P - 1);
   const int64_t src = a.win_order[pq];
   const bool kept = qv && a.win_inverse[src] == pq;
   // stationary fragments: Q^T and dO^T as B operands (lane (i, g): dims 16nd+4g..+3 of query i)
@@ -71,13 +74,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
   dpart += __shfl_xor(dpart, 16, 64);
   const float delta = dpart + __shfl_xor(dpart, 32, 64);
 
-  const int nchunks = (a.patch + CT - 1) / CT;
+  const int nchunks = (P + CT - 1) / CT;
   auto load_chunk = [&](int kc0, bool with_v) {
     __syncthreads();
     for (int u = threadIdx.x; u < CT * (D / 4); u += 256) {
       const int key = u / (D / 4), dv = u % (D / 4);
       V4 kv = zero4<T>(), vv = zero4<T>();
-      if (kc0 + key < a.patch) {
+      if (kc0 + key < P) {
         const int64_t ks = a.win_order[slot0 + kc0 + key];
         kv = *reinterpret_cast<const V4*>(qkv + ks * c3 + a.c + h * D + 4 * dv);
         if (with_v) vv = *reinterpret_cast<const V4*>(qkv + ks * c3 + 2 * a.c + h * D + 4 * dv);
@@ -105,13 +108,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const int kc0 = ch * CT;
     load_chunk(kc0, false);
-    const int ntile = (min(CT, a.patch - kc0) + 15) / 16;
+    const int ntile = (min(CT, P - kc0) + 15) / 16;
     for (int kt = 0; kt < ntile; ++kt) {
       const f32x4 s = scores(kt);
       float t[4], mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        t[r] = kc0 + 16 * kt + 4 * g + r < a.patch ? s[r] * a.scale_log2e : -INFINITY;
+        t[r] = kc0 + 16 * kt + 4 * g + r < P ? s[r] * a.scale_log2e : -INFINITY;
         mx = fmaxf(mx, t[r]);
       }
       if (mx == -INFINITY) continue;
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
   for (int ch = 0; ch < nchunks; ++ch) {
     const int kc0 = ch * CT;
     load_chunk(kc0, true);
-    const int ntile = (min(CT, a.patch - kc0) + 15) / 16;
+    const int ntile = (min(CT, P - kc0) + 15) / 16;
     for (int kt = 0; kt < ntile; ++kt) {
       const f32x4 s = scores(kt);
       f32x4 dp = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -148,7 +151,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = kc0 + 16 * kt + 4 * g + r < a.patch ? __builtin_amdgcn_exp2f(s[r] * a.scale_log2e - lse2) : 0.f;
+        const float p = kc0 + 16 * kt + 4 * g + r < P ? __builtin_amdgcn_exp2f(s[r] * a.scale_log2e - lse2) : 0.f;
         ds[r] = p * (dp[r] - delta);
       }
       const V4 dsv = pack4<T>(ds[0], ds[1], ds[2], ds[3]);
@@ -191,10 +194,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
   const int h = (blockIdx.x / kblocks) % a.heads;
   const int w = blockIdx.x / (kblocks * a.heads);
   const int c3 = 3 * a.c;
-  const int64_t slot0 = (int64_t)w * a.patch;
+  const int64_t slot0 = a.cu ? (int64_t)a.cu[w] : (int64_t)w * a.patch;
+  const int P = a.cu ? a.cu[w + 1] - a.cu[w] : a.patch;  // slots of this window
+  if (kb * 64 >= P) return;                               // workgroup-uniform
   const int jk = kb * 64 + wave * 16 + i;
-  const bool kvalid = jk < a.patch;
-  const int64_t pk = slot0 + (kvalid ? jk : a.patch - 1);
+  const bool kvalid = jk < P;
+  const int64_t pk = slot0 + (kvalid ? jk : P - 1);
   const int64_t src = a.win_order[pk];
   V4 kf[ND], vf[ND];
 #pragma unroll
@@ -206,14 +211,14 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
 #pragma unroll
   for (int nd = 0; nd < ND; ++nd) acck[nd] = accv[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nchunks = (a.patch + CT - 1) / CT;
+  const int nchunks = (P + CT - 1) / CT;
   for (int ch = 0; ch < nchunks; ++ch) {
     const int qc0 = ch * CT;
     __syncthreads();
     for (int u = threadIdx.x; u < CT * (D / 4); u += 256) {
       const int q = u / (D / 4), dv = u % (D / 4);
       V4 qv4 = zero4<T>(), ov4 = zero4<T>();
-      if (qc0 + q < a.patch) {
+      if (qc0 + q < P) {
         const int64_t p = slot0 + qc0 + q;
         const int64_t qs = a.win_order[p];
         qv4 = *reinterpret_cast<const V4*>(qkv + qs * c3 + h * D + 4 * dv);
@@ -231,12 +236,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
       }
     }
     for (int q = threadIdx.x; q < CT; q += 256) {
-      const bool v = qc0 + q < a.patch;
+      const bool v = qc0 + q < P;
       sL[q] = v ? a.lse[(slot0 + qc0 + q) * a.heads + h] : INFINITY;  // exp2(-inf) = 0 for the tail rows
       sDl[q] = v ? a.delta[(slot0 + qc0 + q) * a.heads + h] : 0.f;
     }
     __syncthreads();
-    const int ntile = (min(CT, a.patch - qc0) + 15) / 16;
+    const int ntile = (min(CT, P - qc0) + 15) / 16;
     for (int qt = 0; qt < ntile; ++qt) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -324,23 +329,16 @@ extern "C" size_t ptv3_window_attn_bwd_workspace_bytes(int64_t n, int64_t n_pad,
          align256((size_t)n * sizeof(int32_t));
 }
 
-extern "C" int ptv3_window_attn_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
-                                    const int32_t* win_inverse, void* dqkv, int64_t n, int64_t n_pad, int c, int heads,
-                                    int patch, float scale, int dtype, void* workspace, size_t workspace_bytes,
-                                    void* stream) {
-  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_bwd: c=%d not divisible by heads=%d", c, heads);
-  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_bwd: patch %d outside [1,16384]", patch);
-  PTV3_REQUIRE(n_pad % patch == 0, "window_attn_bwd: n_pad=%lld is not a multiple of patch=%d", (long long)n_pad, patch);
-  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_bwd: bad dtype %d", dtype);
-  PTV3_REQUIRE(workspace_bytes >= ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, heads, dtype),
-               "window_attn_bwd: workspace too small");
+static int window_attn_bwd_impl(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                                const int32_t* win_inverse, const int32_t* cu, int nwin, void* dqkv, int64_t n,
+                                int64_t n_pad, int c, int heads, int patch, float scale, int dtype, void* workspace,
+                                hipStream_t s) {
   const int d = c / heads;
   if (d != 16 && d != 32 && d != 64) {
     set_error("window_attn_bwd: head_dim %d unsupported (16, 32, 64)", d);
     return PTV3_ERR_UNSUPPORTED;
   }
   if (n == 0) return PTV3_OK;
-  hipStream_t s = (hipStream_t)stream;
   const size_t esz = dtype == PTV3_F32 ? 4 : 2;
   char* ws = (char*)workspace;
   AttnBwdArgs a;
@@ -349,7 +347,7 @@ extern "C" int ptv3_window_attn_bwd(const void* qkv, const void* out, const void
   a.lse = (float*)ws; ws += align256((size_t)n_pad * heads * sizeof(float));
   a.delta = (float*)ws; ws += align256((size_t)n_pad * heads * sizeof(float));
   int32_t* dup = (int32_t*)ws;
-  a.c = c; a.heads = heads; a.patch = patch; a.nwin = (int)(n_pad / patch);
+  a.c = c; a.heads = heads; a.patch = patch; a.nwin = nwin; a.cu = cu;
   a.scale = scale; a.scale_log2e = scale * 1.44269504088896340736f;
   if (hipMemsetAsync(dup, 0xFF, (size_t)n * sizeof(int32_t), s) != hipSuccess) return PTV3_ERR_LAUNCH;
   hipLaunchKernelGGL(dup_slot_kernel, dim3((unsigned)cdiv(n_pad, 256)), dim3(256), 0, s, win_order, win_inverse, n_pad, dup);
@@ -370,4 +368,36 @@ extern "C" int ptv3_window_attn_bwd(const void* qkv, const void* out, const void
                        (const __bf16*)a.dqkv_pad, win_inverse, dup, n, 3 * c, (__bf16*)dqkv);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
+}
+
+extern "C" int ptv3_window_attn_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                                    const int32_t* win_inverse, void* dqkv, int64_t n, int64_t n_pad, int c, int heads,
+                                    int patch, float scale, int dtype, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_bwd: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_bwd: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(n_pad % patch == 0, "window_attn_bwd: n_pad=%lld is not a multiple of patch=%d", (long long)n_pad, patch);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_bwd: bad dtype %d", dtype);
+  PTV3_REQUIRE(workspace_bytes >= ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, heads, dtype),
+               "window_attn_bwd: workspace too small");
+  return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, nullptr, (int)(n_pad / patch), dqkv, n, n_pad, c,
+                              heads, patch, scale, dtype, workspace, (hipStream_t)stream);
+}
+
+extern "C" int ptv3_window_attn_varlen_bwd(const void* qkv, const void* out, const void* dout,
+                                           const int32_t* win_order, const int32_t* win_inverse,
+                                           const int32_t* cu_seqlens, int num_windows, void* dqkv, int64_t n,
+                                           int64_t n_pad, int c, int heads, int max_seqlen, float scale, int dtype,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_varlen_bwd: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(max_seqlen >= 1 && max_seqlen <= 16384, "window_attn_varlen_bwd: max_seqlen %d outside [1,16384]", max_seqlen);
+  PTV3_REQUIRE(cu_seqlens != nullptr && num_windows >= 1, "window_attn_varlen_bwd: cu_seqlens with >= 1 window required");
+  PTV3_REQUIRE(n_pad <= (int64_t)num_windows * max_seqlen && n_pad >= num_windows,
+               "window_attn_varlen_bwd: n_pad=%lld cannot be split into %d windows of 1..%d slots", (long long)n_pad,
+               num_windows, max_seqlen);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_varlen_bwd: bad dtype %d", dtype);
+  PTV3_REQUIRE(workspace_bytes >= ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, heads, dtype),
+               "window_attn_varlen_bwd: workspace too small");
+  return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, cu_seqlens, num_windows, dqkv, n, n_pad, c, heads,
+                              max_seqlen, scale, dtype, workspace, (hipStream_t)stream);
 }

@@ -81,7 +81,12 @@ __global__ void batch_from_offset_kernel(const int64_t* __restrict__ offset, int
   batch[i] = lo;
 }
 
-struct Plan { int K = -1; int64_t n_pad = 0; int32_t* wo[8] = {nullptr}; int32_t* wi[8] = {nullptr}; };
+// window plan of one (level, patch): cu != nullptr when some scene is shorter than the patch (enable_flash=True
+// keeps K fixed, so such a scene is ONE short window, v3m1_base.py:131-133) -> ragged-window attention
+struct Plan {
+  int K = -1; int64_t n_pad = 0; int32_t* wo[8] = {nullptr}; int32_t* wi[8] = {nullptr};
+  int32_t* cu = nullptr; int nwin = 0; double sum_len_sq = 0.0;
+};
 
 struct Level {
   int64_t n = 0; int depth = 0;
@@ -99,28 +104,53 @@ struct Level {
   void* feat = nullptr; void* conv_feat = nullptr; int channels = 0;
 };
 
-static hipStream_t g_geo_stream = nullptr;
-static hipStream_t g_feat_stream[2] = {nullptr, nullptr};  // overlap_calls: feature pipelines of consecutive calls
-static std::vector<hipEvent_t> g_events;
-static unsigned g_call = 0;  // calls alternate between the two geometry arenas (see ptv3_forward)
-static double g_sync_us = 0.0;  // host time blocked in geometry-stream read-backs (PTV3_ENGINE_TIMING=1)
 static inline double now_us() {
   return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
-static hipError_t timed_sync(hipStream_t s) {
-  double t = now_us();
-  hipError_t e = hipStreamSynchronize(s);
-  g_sync_us += now_us() - t;
-  return e;
-}
 
-static hipEvent_t event_at(size_t i) {
-  while (g_events.size() <= i) {
-    hipEvent_t e;
-    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    g_events.push_back(e);
+// Executor state: the streams, events, call parity and overlap handshake of ONE executor.  An executor belongs to
+// one device; a model that wants its forwards ordered independently of every other model in the process creates its
+// own (ptv3_executor_create, ptv3_forward_io.executor), otherwise the device's default executor is used.  Calls on
+// one executor take turns on the host (mutex) and overlap on the GPU as consecutive calls of one thread do.
+struct Exec {
+  int device = 0;
+  hipStream_t geo = nullptr;
+  hipStream_t feat[2] = {nullptr, nullptr};  // overlap_calls: feature pipelines of consecutive calls
+  std::vector<hipEvent_t> events;
+  unsigned call = 0;          // calls alternate between the two geometry arenas (see ptv3_forward)
+  bool last_overlap = false;  // mode of the previous call (the overlap handshake reruns after a stream-ordered call)
+  double sync_us = 0.0;       // host time blocked in geometry-stream read-backs (PTV3_ENGINE_TIMING=1)
+  std::mutex mu;
+  hipError_t timed_sync(hipStream_t s) {
+    double t = now_us();
+    hipError_t e = hipStreamSynchronize(s);
+    sync_us += now_us() - t;
+    return e;
   }
-  return g_events[i];
+  hipEvent_t event_at(size_t i) {
+    while (events.size() <= i) {
+      hipEvent_t e;
+      (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      events.push_back(e);
+    }
+    return events[i];
+  }
+  void release() {
+    if (geo) { (void)hipStreamSynchronize(geo); (void)hipStreamDestroy(geo); geo = nullptr; }
+    for (auto& f : feat) if (f) { (void)hipStreamSynchronize(f); (void)hipStreamDestroy(f); f = nullptr; }
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    events.clear();
+  }
+};
+static std::mutex g_exec_mutex;
+static std::vector<Exec*> g_default_exec;  // one per device, created on first use
+static Exec* default_exec() {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> guard(g_exec_mutex);
+  if ((int)g_default_exec.size() <= dev) g_default_exec.resize(dev + 1, nullptr);
+  if (!g_default_exec[dev]) { g_default_exec[dev] = new Exec(); g_default_exec[dev]->device = dev; }
+  return g_default_exec[dev];
 }
 
 // (n, cin) rows in their original dtype -> (n, cpad) rows of the compute dtype, zero-padded
@@ -144,6 +174,7 @@ static void pad_cast(const void* x, int sdt, int cin, void* y, int ddt, int cpad
 }
 
 struct Run {
+  Exec* X;
   const ptv3_model_desc* d; const void* const* params; int pi = 0;
   Arena* G; Arena* F;            // geometry / feature arenas
   hipStream_t sg, sf;            // geometry / feature streams
@@ -178,10 +209,22 @@ struct Run {
       prev = o;
     }
     P.K = K; P.n_pad = n_pad;
+    bool ragged = false;
+    P.nwin = 0; P.sum_len_sq = 0.0; prev = 0;
+    for (int64_t o : L.off_host) {
+      const int64_t cnt = o - prev;
+      prev = o;
+      P.nwin += (int)((cnt + K - 1) / K);
+      if (cnt < K) { ragged = true; P.sum_len_sq += (double)cnt * cnt; }
+      else P.sum_len_sq += (double)((cnt + K - 1) / K) * K * K;
+    }
     const int k = d->num_orders;
     int32_t* wo = (int32_t*)G->alloc((size_t)k * n_pad * 4);
     int32_t* wi = (int32_t*)G->alloc((size_t)k * L.n * 4);
-    RUN(ptv3_window_plan(L.order, L.inverse, L.offset, (int)L.off_host.size(), k, L.n, n_pad, K, wo, wi, sg));
+    // dry run: reserve the table whenever the flag allows short windows (the sizes are not known yet)
+    P.cu = (ragged || (dry && d->enable_flash)) ? (int32_t*)G->alloc(((size_t)P.nwin + L.off_host.size() + 1) * 4) : nullptr;
+    if (!ragged && !dry) P.cu = nullptr;
+    RUN(ptv3_window_plan(L.order, L.inverse, L.offset, (int)L.off_host.size(), k, L.n, n_pad, K, wo, wi, P.cu, sg));
     for (int i = 0; i < k; ++i) { P.wo[i] = wo + (int64_t)i * n_pad; P.wi[i] = wi + (int64_t)i * L.n; }
   }
 
@@ -209,6 +252,16 @@ struct Run {
       const int Kd = patch_K(L, d->dec_patch[st]);
       if (Kd == Ke) L.plan[1] = L.plan[0]; else window_plan(L, L.plan[1], Kd);
     }
+  }
+
+  // SerializedAttention core (:184-216): uniform K-slot windows, or ragged ones (a scene shorter than the fixed patch
+  // of enable_flash=True is one short window, :131-133 + the varlen call :207-215)
+  void attention(const Level& L, const Plan& P, const void* qkv, void* out, int C, int H, int oi, float scale) {
+    if (P.cu)
+      RUN(ptv3_window_attn_varlen_fwd(qkv, P.wo[oi], P.wi[oi], P.cu, P.nwin, out, L.n, P.n_pad, C, H, P.K, scale,
+                                      P.sum_len_sq, d->dtype, sf));
+    else
+      RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], out, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
   }
 
   // Block.forward (:318-338), eval, pre_norm; cpe Linear folded into the conv taps
@@ -242,7 +295,7 @@ struct Run {
         RUN(ptv3_block_head(t2, nullptr, 0, nullptr, L.feat, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b, f1, qkv, L.n, C,
                             d->ln_eps, d->dtype, sf));
       }
-      RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
+      attention(L, P, qkv, t4, C, H, oi, scale);
       RUN(ptv3_block_tail(t4, f1, proj_w, proj_b, n2_g, n2_b, fc1_w, fc1_b, fc2_w, fc2_b, L.feat, L.n, C, hidden,
                           d->ln_eps, d->dtype, sf));
     } else {
@@ -263,7 +316,7 @@ struct Run {
         RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
       }
       gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
-      RUN(ptv3_window_attn_fwd(qkv, P.wo[oi], P.wi[oi], t4, L.n, P.n_pad, C, H, P.K, scale, nullptr, d->dtype, sf));
+      attention(L, P, qkv, t4, C, H, oi, scale);
       gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
       RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, sf));
       gemm(t5, fc1_w, t6, L.n, C, hidden, 1, nullptr, nullptr, fc1_b, nullptr, nullptr, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
@@ -276,34 +329,34 @@ struct Run {
 
 #define RUNR(call) do { if (!dry && R.ok()) { int r__ = (call); if (r__) R.rc = r__; } } while (0)
 
-static int run_forward(const ptv3_model_desc* d, const void* const* params, const ptv3_forward_io* io, Arena& G,
+static int run_forward(Exec* X, const ptv3_model_desc* d, const void* const* params, const ptv3_forward_io* io, Arena& G,
                        Arena& F, hipStream_t sf, bool dry, int* param_count = nullptr) {
-  Run R; R.d = d; R.params = params; R.G = &G; R.F = &F; R.sf = sf; R.dry = dry;
+  Run R; R.X = X; R.d = d; R.params = params; R.G = &G; R.F = &F; R.sf = sf; R.dry = dry;
   R.es = d->dtype == PTV3_F32 ? 4 : 2;
   const int S = d->num_stages, k = d->num_orders, es = R.es;
   if (!dry) {
-    if (!g_geo_stream) {
+    if (!X->geo) {
       // highest priority: the geometry chain is a string of tiny dependent kernels whose read-backs gate the
       // host; its workgroups must not queue behind the long feature kernels of the other stream
       int least = 0, greatest = 0;
       (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-      if (hipStreamCreateWithPriority(&g_geo_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+      if (hipStreamCreateWithPriority(&X->geo, hipStreamNonBlocking, greatest) != hipSuccess) {
         set_error("forward: cannot create the geometry stream");
         return PTV3_ERR_LAUNCH;
       }
     }
     if (!io->inputs_resident) {
       // coordinates / offsets may have been produced on the caller's stream just before this call
-      hipEvent_t e = event_at(0);
+      hipEvent_t e = X->event_at(0);
       (void)hipEventRecord(e, sf);
-      (void)hipStreamWaitEvent(g_geo_stream, e, 0);
+      (void)hipStreamWaitEvent(X->geo, e, 0);
     } else {
       // inputs already materialised: geometry of this call may overlap the feature tail of the previous one;
       // it only has to wait for the call that last used THIS geometry arena (two calls ago)
-      (void)hipStreamWaitEvent(g_geo_stream, event_at(20 + (g_call & 1)), 0);
+      (void)hipStreamWaitEvent(X->geo, X->event_at(20 + (X->call & 1)), 0);
     }
   }
-  R.sg = g_geo_stream;
+  R.sg = dry ? nullptr : X->geo;
   hipStream_t sg = R.sg;
   std::vector<Level> lv(S);
   const int nbits = io->b > 1 ? 32 - __builtin_clz((unsigned)(io->b - 1)) : 0;
@@ -330,7 +383,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
     if (io->offset_host) std::copy(io->offset_host, io->offset_host + io->b, L0.off_host.begin());
     else (void)hipMemcpyAsync(L0.off_host.data(), io->offset, (size_t)io->b * 8, hipMemcpyDeviceToHost, sg);
     if (dmax || !io->offset_host) {
-      if (timed_sync(sg) != hipSuccess) { set_error("forward: input read-back failed"); return PTV3_ERR_LAUNCH; }
+      if (X->timed_sync(sg) != hipSuccess) { set_error("forward: input read-back failed"); return PTV3_ERR_LAUNCH; }
     }
     if (dmax) { depth = 0; for (unsigned v = (unsigned)hmax + 1; v; v >>= 1) ++depth; }
     PTV3_REQUIRE(depth >= 1 && depth <= 16, "forward: serialization depth %d outside [1,16] (structure.py:81)", depth);
@@ -355,7 +408,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
   }
   R.level_geometry(L0, 0, io->grid_coord, io->coord_is_i64, true);
   if (io->stage_points_host) io->stage_points_host[0] = L0.n;
-  if (!dry && R.ok()) { L0.ready = event_at(1); (void)hipEventRecord(L0.ready, sg); }
+  if (!dry && R.ok()) { L0.ready = X->event_at(1); (void)hipEventRecord(L0.ready, sg); }
 
   // ---------------- features of level 0 start as soon as its geometry is queued
   auto wait_level = [&](Level& L) { if (!dry && R.ok()) (void)hipStreamWaitEvent(sf, L.ready, 0); };
@@ -400,7 +453,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
         L.off_host = P.off_host;  // worst case: nothing merges
       } else if (R.ok()) {
         if (hipMemcpyAsync(L.off_host.data(), poff, (size_t)io->b * 8, hipMemcpyDeviceToHost, sg) != hipSuccess ||
-            timed_sync(sg) != hipSuccess) { set_error("forward: offset read-back failed"); return PTV3_ERR_LAUNCH; }
+            X->timed_sync(sg) != hipSuccess) { set_error("forward: offset read-back failed"); return PTV3_ERR_LAUNCH; }
       }
       if (!R.ok()) break;
       L.n = L.off_host[io->b - 1]; L.depth = P.depth - pd; L.offset = poff; L.channels = C;
@@ -425,7 +478,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
         if (!dry && R.ok())
           hipLaunchKernelGGL(i64_to_i32_kernel, dim3((unsigned)cdiv(P.n, 256)), dim3(256), 0, sg, P.cluster, P.cluster32, P.n);
       }
-      if (!dry && R.ok()) { L.ready = event_at(1 + st); (void)hipEventRecord(L.ready, sg); }
+      if (!dry && R.ok()) { L.ready = X->event_at(1 + st); (void)hipEventRecord(L.ready, sg); }
       // ---- features of the pooled level: proj -> segmented max + folded BN + GELU (:416-418, 439-442)
       wait_level(L);
       L.feat = F.alloc((size_t)L.n * C * es);
@@ -499,7 +552,7 @@ static int run_forward(const ptv3_model_desc* d, const void* const* params, cons
   }
   if (!dry && R.ok() && !d->enc_mode && io->out_feat && lv[0].feat != io->out_feat)
     (void)hipMemcpyAsync(io->out_feat, lv[0].feat, (size_t)lv[0].n * lv[0].channels * es, hipMemcpyDeviceToDevice, sf);
-  if (!dry) (void)hipEventRecord(event_at(20 + (g_call & 1)), sf);  // this call's readers of its geometry arena
+  if (!dry) (void)hipEventRecord(X->event_at(20 + (X->call & 1)), sf);  // this call's readers of its geometry arena
   if (param_count) *param_count = R.pi;
   if (G.failed || F.failed) { set_error("forward: workspace arena too small"); return PTV3_ERR_ARG; }
   if (R.rc) return R.rc;
@@ -522,7 +575,7 @@ static void plan_bytes(const ptv3_model_desc* desc, int64_t n, int b, size_t* ge
   io.n = n; io.b = b; io.depth = 0; io.order_ids_host = ids.data(); io.pool_perm_host = perm.data();
   io.coord_is_i64 = 1;
   Arena G{nullptr, 0, 0, 0, true, false}, F{nullptr, 0, 0, 0, true, false};
-  run_forward(desc, nullptr, &io, G, F, nullptr, true, count);
+  run_forward(nullptr, desc, nullptr, &io, G, F, nullptr, true, count);
   // slack: every scene may gain up to one window of borrowed rows per window plan
   *geo = (G.peak + (size_t)b * 16384 * 64 + (1 << 20) + 255) / 256 * 256;
   *feat = (F.peak + (1 << 20) + 255) / 256 * 256;
@@ -539,12 +592,33 @@ extern "C" size_t ptv3_forward_workspace_bytes(const ptv3_model_desc* desc, int6
   return 2 * g + 2 * f + 512;  // two geometry arenas (consecutive calls alternate), two feature arenas (overlap_calls)
 }
 
+extern "C" void* ptv3_executor_create(void) {
+  Exec* X = new Exec();
+  (void)hipGetDevice(&X->device);
+  return X;
+}
+
+extern "C" int ptv3_executor_destroy(void* executor) {
+  Exec* X = (Exec*)executor;
+  if (!X) return PTV3_OK;
+  {
+    std::lock_guard<std::mutex> guard(X->mu);  // no call of this executor is on the host any more
+    X->release();                                // drains its streams first
+  }
+  delete X;
+  return PTV3_OK;
+}
+
 extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num_params,
                             const ptv3_forward_io* io, void* workspace, size_t workspace_bytes, void* stream) {
-  // the executor's streams, events, call parity and arena halves are process-wide: calls from several host threads
-  // take turns (they still overlap on the GPU exactly as consecutive calls of one thread do)
-  static std::mutex g_forward_mutex;
-  std::lock_guard<std::mutex> guard(g_forward_mutex);
+  // streams, events, call parity and arena halves belong to an executor (io->executor, or the current device's
+  // default one): calls on ONE executor from several host threads take turns (they still overlap on the GPU exactly
+  // as consecutive calls of one thread do); different executors are independent
+  Exec* X = io->executor ? (Exec*)io->executor : default_exec();
+  std::lock_guard<std::mutex> guard(X->mu);
+  int cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  PTV3_REQUIRE(cur_dev == X->device, "forward: executor belongs to device %d, the current device is %d", X->device, cur_dev);
   if (int r = check_desc(desc)) return r;
   PTV3_REQUIRE(io->n >= 1 && io->b >= 1, "forward: empty batch");
   PTV3_REQUIRE(io->depth <= 16, "forward: depth %d > 16", io->depth);
@@ -575,42 +649,42 @@ extern "C" int ptv3_forward(const ptv3_model_desc* desc, const void* const* para
                workspace_bytes, need);
   char* base = (char*)workspace;
   size_t goff = (256 - ((uintptr_t)base & 255)) & 255;
-  ++g_call;
+  ++X->call;
   static const bool timing = getenv("PTV3_ENGINE_TIMING") != nullptr;
   const double t_begin = timing ? now_us() : 0.0;
-  g_sync_us = 0.0;
-  event_at(21);  // make sure the two arena events exist (an unrecorded event never blocks a wait)
-  const unsigned par = g_call & 1;
+  X->sync_us = 0.0;
+  X->event_at(21);  // make sure the two arena events exist (an unrecorded event never blocks a wait)
+  const unsigned par = X->call & 1;
   hipStream_t caller = (hipStream_t)stream, sf = caller;
   if (overlap) {
-    if (!g_feat_stream[par] && hipStreamCreateWithFlags(&g_feat_stream[par], hipStreamNonBlocking) != hipSuccess) {
+    if (!X->feat[par] && hipStreamCreateWithFlags(&X->feat[par], hipStreamNonBlocking) != hipSuccess) {
       set_error("forward: cannot create the feature stream");
       return PTV3_ERR_LAUNCH;
     }
-    sf = g_feat_stream[par];
-    event_at(34);
-    static bool last_overlap = false;
-    if (!last_overlap) {
-      // first overlapped call after stream-ordered ones: those ran their feature pipeline on the caller's stream out
-      // of the first feature arena - order the executor's streams behind them once
-      (void)hipEventRecord(event_at(34), caller);
+    sf = X->feat[par];
+    X->event_at(34);
+    if (!X->last_overlap) {
+      // first overlapped call after a stream-ordered one (or the first call at all): that call ran its feature
+      // pipeline on the caller's stream out of the first feature arena - order the executor's streams behind it.
+      // Reruns after EVERY stream-ordered call (last_overlap is the mode of the previous call, set below).
+      (void)hipEventRecord(X->event_at(34), caller);
       for (int q = 0; q < 2; ++q)
-        if (g_feat_stream[q]) (void)hipStreamWaitEvent(g_feat_stream[q], event_at(34), 0);
-      last_overlap = true;
+        if (X->feat[q]) (void)hipStreamWaitEvent(X->feat[q], X->event_at(34), 0);
     }
     // the output buffers this call overwrites were last read by work the caller enqueued before the PREVIOUS call
     // started (contract in the header): wait for that marker, never for the previous call itself
-    (void)hipStreamWaitEvent(sf, event_at(30 + (par ^ 1)), 0);
-    (void)hipEventRecord(event_at(30 + par), caller);
+    (void)hipStreamWaitEvent(sf, X->event_at(30 + (par ^ 1)), 0);
+    (void)hipEventRecord(X->event_at(30 + par), caller);
   }
+  X->last_overlap = overlap;
   Arena G{base + goff + par * g, g, 0, 0, false, false};
   Arena F{base + goff + 2 * g + (overlap ? par * f : 0), f, 0, 0, false, false};
-  int rc = run_forward(desc, params, io, G, F, sf, false, nullptr);
+  int rc = run_forward(X, desc, params, io, G, F, sf, false, nullptr);
   if (overlap) {
-    (void)hipEventRecord(event_at(32 + par), sf);
-    (void)hipStreamWaitEvent(caller, event_at(32 + par), 0);  // the caller's later work sees this call's outputs
+    (void)hipEventRecord(X->event_at(32 + par), sf);
+    (void)hipStreamWaitEvent(caller, X->event_at(32 + par), 0);  // the caller's later work sees this call's outputs
   }
   if (timing)
-    fprintf(stderr, "[ptv3_forward] host %.0f us total, %.0f us blocked in read-backs\n", now_us() - t_begin, g_sync_us);
+    fprintf(stderr, "[ptv3_forward] host %.0f us total, %.0f us blocked in read-backs\n", now_us() - t_begin, X->sync_us);
   return rc;
 }

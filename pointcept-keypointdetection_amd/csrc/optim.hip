@@ -15,6 +15,9 @@ struct AdamWTensor {
   // Linear (kvol = 1) and the mirrored-tap transposed weight of a SubMConv3d input gradient
   void* shadow; void* shadow_t;
   int32_t rows, cols, kvol, shadow_dtype;
+  // steps this tensor has taken fewer than the launch's `step` argument (a parameter that joined the table late, or
+  // was restored from a checkpoint with its own torch.optim state["step"]): bias corrections use step - step_lag
+  int32_t step_lag, reserved;
 };
 
 struct AdamWGroups { float lr[8], wd[8]; };
@@ -23,7 +26,7 @@ constexpr int ADAMW_CHUNK = 4096;  // elements per block
 
 __global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restrict__ tab, int ntensors,
                                                      AdamWGroups grp, float beta1, float beta2, float eps,
-                                                     float bc1, float rsqrt_bc2, float grad_scale) {
+                                                     float bc1, float rsqrt_bc2, float grad_scale, float step_no) {
   // find the tensor owning this block
   int lo = 0, hi = ntensors - 1;
   while (lo < hi) {
@@ -33,6 +36,11 @@ __global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restric
   const AdamWTensor t = tab[lo];
   const int64_t base = (int64_t)(blockIdx.x - t.first_block) * ADAMW_CHUNK;
   const float lr = grp.lr[t.group], wd = grp.wd[t.group];
+  if (t.step_lag != 0) {  // this tensor's own step count (block-uniform branch)
+    const float own = step_no - (float)t.step_lag;
+    bc1 = 1.0f - powf(beta1, own);
+    rsqrt_bc2 = rsqrtf(1.0f - powf(beta2, own));
+  }
   const float step = lr / bc1;
   for (int64_t j = base + threadIdx.x; j < base + ADAMW_CHUNK && j < t.numel; j += 256) {
     const float g = t.g[j] * grad_scale;
@@ -112,6 +120,13 @@ extern "C" int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* 
   e->p = (float*)param; e->g = (const float*)grad; e->m = (float*)exp_avg; e->v = (float*)exp_avg_sq;
   e->numel = numel; e->group = group; e->first_block = first_block;
   e->shadow = nullptr; e->shadow_t = nullptr; e->rows = e->cols = e->kvol = 0; e->shadow_dtype = PTV3_F32;
+  e->step_lag = 0; e->reserved = 0;
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_adamw_fill_step_lag(void* entry_host, int64_t step_lag) {
+  PTV3_REQUIRE(step_lag >= 0 && step_lag < (1ll << 31), "adamw: step_lag %lld outside [0, 2^31)", (long long)step_lag);
+  ((AdamWTensor*)entry_host)->step_lag = (int32_t)step_lag;
   return PTV3_OK;
 }
 
@@ -139,7 +154,7 @@ extern "C" int ptv3_adamw_step(const void* table_dev, int ntensors, int total_bl
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                      (const AdamWTensor*)table_dev, ntensors, grp, beta1, beta2, eps, (float)bc1,
-                     (float)(1.0 / sqrt(bc2)), grad_scale);
+                     (float)(1.0 / sqrt(bc2)), grad_scale, (float)step);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

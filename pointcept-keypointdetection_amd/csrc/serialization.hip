@@ -296,7 +296,8 @@ __global__ void window_maps_kernel(const int64_t* __restrict__ order, const int6
 // pad plan and both window maps for all k orders in one pass, without materialising pad / unpad
 __global__ void window_plan_kernel(const int64_t* __restrict__ order, const int64_t* __restrict__ inverse,
                                    const int64_t* __restrict__ offset, int b, int k, int64_t n, int64_t n_pad,
-                                   int K, int32_t* __restrict__ wo, int32_t* __restrict__ wi) {
+                                   int K, int32_t* __restrict__ wo, int32_t* __restrict__ wi,
+                                   int32_t* __restrict__ cu) {
   extern __shared__ int64_t tab[];
   int64_t* s_off = tab;
   int64_t* s_offp = tab + (b + 1);
@@ -330,6 +331,22 @@ __global__ void window_plan_kernel(const int64_t* __restrict__ order, const int6
       wi[(int64_t)r * n + p] = (int32_t)(j + (s_offp[lo] - s_off[lo]));  // = unpad[j]
     }
   }
+  if (cu && p <= n_pad) {  // window starts: concat_i arange(offp_i, offp_{i+1}, K), then n_pad (:155-169)
+    if (p == n_pad) {
+      int64_t e = 0;
+      for (int i = 0; i < b; ++i) e += (s_offp[i + 1] - s_offp[i] + K - 1) / K;
+      cu[e] = (int32_t)n_pad;
+    } else {
+      int lo = 0, hi = b;
+      while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (s_offp[mid] <= p) lo = mid; else hi = mid; }
+      const int64_t local = p - s_offp[lo];
+      if (local % K == 0) {
+        int64_t e = local / K;
+        for (int i = 0; i < lo; ++i) e += (s_offp[i + 1] - s_offp[i] + K - 1) / K;
+        cu[e] = (int32_t)p;
+      }
+    }
+  }
 }
 
 }  // namespace ptv3
@@ -338,14 +355,14 @@ using namespace ptv3;
 
 extern "C" int ptv3_window_plan(const int64_t* order, const int64_t* inverse, const int64_t* offset, int b, int k,
                                 int64_t n, int64_t n_pad, int patch, int32_t* win_order, int32_t* win_inverse,
-                                void* stream) {
+                                int32_t* cu_seqlens, void* stream) {
   PTV3_REQUIRE(b >= 1 && b <= 4096, "window_plan: batch size %d outside [1,4096]", b);
   PTV3_REQUIRE(k >= 1 && k <= 8 && patch >= 1, "window_plan: bad k / patch");
-  int64_t work = n_pad > n ? n_pad : n;
+  int64_t work = (n_pad > n ? n_pad : n) + (cu_seqlens ? 1 : 0);
   if (work == 0) return PTV3_OK;
   hipLaunchKernelGGL(window_plan_kernel, dim3((unsigned)cdiv(work, 256)), dim3(256),
                      (size_t)2 * (b + 1) * sizeof(int64_t), (hipStream_t)stream, order, inverse, offset, b, k, n, n_pad,
-                     patch, win_order, win_inverse);
+                     patch, win_order, win_inverse, cu_seqlens);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -25,8 +25,9 @@ template <typename T> struct WaCfg<T, 4> { static constexpr int QT = 1; };
 template <typename T, int ND>
 __global__ void __launch_bounds__(WA_THREADS)
 window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
-                   const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
-                   int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe) {
+                   const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int Kmax,
+                   int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe,
+                   const int32_t* __restrict__ cu) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
@@ -49,8 +50,11 @@ window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_or
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t wbase = (int64_t)w * K;
+  // varlen (cu != nullptr): window w holds the padded slots [cu[w], cu[w+1]), at most Kmax of them
+  const int64_t wbase = cu ? (int64_t)cu[w] : (int64_t)w * Kmax;
+  const int K = cu ? cu[w + 1] - cu[w] : Kmax;
   const int C3 = 3 * C;
+  if (qs * QB >= K) return;  // workgroup-uniform: a short window needs fewer query blocks
 
   for (int i = tid; i < K; i += WA_THREADS) sOrd[i] = win_order[wbase + i];
   __syncthreads();
@@ -263,9 +267,9 @@ struct RpeTable { const int32_t* grid; const float* table; int pos_bnd; };
 template <typename T, int ND, int RPE, int QT>
 __global__ void __launch_bounds__(512)
 window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
-                        const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int K,
+                        const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int Kmax,
                         int Kpad, int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe,
-                        RpeTable rt) {
+                        RpeTable rt, const int32_t* __restrict__ cu) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
   constexpr int KS = D + 4;
@@ -291,13 +295,18 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
-  const int64_t wbase = (int64_t)w * K;
+  // varlen (cu != nullptr; flash_attn_varlen semantics, v3m1_base.py:207-215): window w holds the padded slots
+  // [cu[w], cu[w+1]), at most Kmax of them; the LDS layout stays that of a Kmax-key window
+  const int64_t wbase = cu ? (int64_t)cu[w] : (int64_t)w * Kmax;
+  const int K = cu ? cu[w + 1] - cu[w] : Kmax;
+  const int Kst = (K + WA_KT - 1) / WA_KT * WA_KT;  // staged rows of THIS window (<= Kpad)
   const int C3 = 3 * C;
+  if (qs * QB >= K) return;  // workgroup-uniform: a short window needs fewer query blocks
 
-  for (int i = tid; i < Kpad; i += nthreads) sOrd[i] = i < K ? win_order[wbase + i] : -1;
+  for (int i = tid; i < Kst; i += nthreads) sOrd[i] = i < K ? win_order[wbase + i] : -1;
   __syncthreads();
   if constexpr (RPE == 2) {
-    for (int i = tid; i < Kpad; i += nthreads) {
+    for (int i = tid; i < Kst; i += nthreads) {
       const int row = sOrd[i];
 #pragma unroll
       for (int d = 0; d < 3; ++d) sGC[3 * i + d] = row >= 0 ? rt.grid[(int64_t)row * 3 + d] : 0;
@@ -309,7 +318,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   // write; a 1024-key window at head_dim 16 is ONE pass of 8 loads per thread for an 8-wave workgroup (the gathers
   // are latency-bound: two dependent passes cost two round trips)
   constexpr int CH = D / 4;
-  const int total = Kpad * CH;
+  const int total = Kst * CH;
   auto stage_pass = [&](const int e0, auto unroll_tag) {
     constexpr int U = decltype(unroll_tag)::value;
     V4 rk[U], rv[U];
@@ -517,7 +526,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
 // (cycles on the busiest CU) over the candidates; PTV3_ATTN_WAVES / PTV3_ATTN_QT force a choice for experiments.
 template <typename T> struct FullArgs {
   const T* qkv; const int32_t* wo; const int32_t* wi; T* out; int C, H, K, Kpad, nwin; float scale_log2e;
-  const float* rpe; RpeTable rt; int waves; size_t lds; hipStream_t s;
+  const float* rpe; RpeTable rt; int waves; size_t lds; hipStream_t s; const int32_t* cu;
 };
 
 template <typename T, int ND, int RPE, int QT>
@@ -532,7 +541,7 @@ static void launch_full(const FullArgs<T>& a) {
   const int qsplit = (a.K + QB - 1) / QB;
   const unsigned nwg = (unsigned)a.nwin * a.H * qsplit;
   hipLaunchKernelGGL((window_attn_full_kernel<T, ND, RPE, QT>), dim3(nwg), dim3(a.waves * 64), a.lds, a.s, a.qkv, a.wo,
-                     a.wi, a.out, a.C, a.H, a.K, a.Kpad, a.nwin, qsplit, a.scale_log2e, a.rpe, a.rt);
+                     a.wi, a.out, a.C, a.H, a.K, a.Kpad, a.nwin, qsplit, a.scale_log2e, a.rpe, a.rt, a.cu);
 }
 
 template <typename T, int ND, int QT>
@@ -581,7 +590,7 @@ static void full_config(int64_t pairs, int K, int qt_max, size_t lds, int* waves
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
                               int K, int nwin, float scale, const float* rpe, hipStream_t s,
-                              RpeTable rt = RpeTable{nullptr, nullptr, 0}) {
+                              RpeTable rt = RpeTable{nullptr, nullptr, 0}, const int32_t* cu = nullptr) {
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
   const int Kpad = (K + WA_KT - 1) / WA_KT * WA_KT;
@@ -595,7 +604,7 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
     int waves, qt;
     full_config(nwin * (int64_t)H, K, WaCfg<T, ND>::QT, lds_full, &waves, &qt);
     const FullArgs<T> a{(const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, scale * 1.44269504088896340736f, rpe,
-                        rt, waves, lds_full, s};
+                        rt, waves, lds_full, s, cu};
     const int rpe_mode = rt.table ? 2 : (rpe ? 1 : 0);
     constexpr int QTMAX = WaCfg<T, ND>::QT;
     if (qt >= 4 && QTMAX >= 4) launch_full_rpe<T, ND, (QTMAX >= 4 ? 4 : QTMAX)>(a, rpe_mode);
@@ -609,7 +618,7 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
   const size_t lds = (size_t)(WA_KT * (D + 4) + D * (WA_KT + 4)) * sizeof(T) + (size_t)K * 4;
   const unsigned nwg = (unsigned)nwin * H * qsplit;
   hipLaunchKernelGGL((window_attn_kernel<T, ND>), dim3(nwg), dim3(WA_THREADS), lds, s, (const T*)qkv, wo, wi,
-                     (T*)out, C, H, K, nwin, qsplit, scale * 1.44269504088896340736f, rpe);
+                     (T*)out, C, H, K, nwin, qsplit, scale * 1.44269504088896340736f, rpe, cu);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }
@@ -618,38 +627,60 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
 
 using namespace ptv3;
 
-extern "C" int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
-                                    void* out, int64_t n, int64_t n_pad, int c, int heads, int patch,
-                                    float scale, const float* rpe_bias, int dtype, void* stream) {
-  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn: c=%d not divisible by heads=%d", c, heads);
-  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn: patch %d outside [1,16384]", patch);
-  PTV3_REQUIRE(n_pad % patch == 0, "window_attn: n_pad=%lld is not a multiple of patch=%d", (long long)n_pad,
-               patch);
-  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn: bad dtype %d", dtype);
+static int window_attn_fwd_impl(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                const int32_t* cu, int nwin, void* out, int64_t n, int64_t n_pad, int c, int heads,
+                                int patch, float scale, const float* rpe_bias, int dtype, double flops, hipStream_t s) {
   const int d = c / heads;
   if (n == 0) return PTV3_OK;
-  const int nwin = (int)(n_pad / patch);
-  hipStream_t s = (hipStream_t)stream;
   if (d != 16 && d != 32 && d != 64) {
     set_error("window_attn: head_dim %d unsupported (16, 32, 64)", d);
     return PTV3_ERR_UNSUPPORTED;
   }
   const int esz = dtype == PTV3_F32 ? 4 : 2;
-  // algorithmic work: 4*n_pad*patch*c flops; qkv read + out write + the two index maps
-  const int prof = prof_begin(s, PROF_WINDOW_ATTN, 4.0 * n_pad * patch * c,
+  // algorithmic work: 4 * sum_w len_w^2 * c flops; qkv read + out write + the two index maps
+  const int prof = prof_begin(s, PROF_WINDOW_ATTN, flops,
                               (double)n_pad * 3 * c * esz + (double)n * c * esz + 4.0 * (n_pad + n), nullptr, 0, 0.0);
   int rc = PTV3_ERR_UNSUPPORTED;
+  const RpeTable none{nullptr, nullptr, 0};
 #define WA_CASE(T)                                                                                          \
   switch (d) {                                                                                              \
-    case 16: rc = launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); break; \
-    case 32: rc = launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); break; \
-    case 64: rc = launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s); break; \
+    case 16: rc = launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu); break; \
+    case 32: rc = launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu); break; \
+    case 64: rc = launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu); break; \
     default: break;                                                                                         \
   }
   if (dtype == PTV3_F32) { WA_CASE(float) } else { WA_CASE(__bf16) }
 #undef WA_CASE
   prof_end(prof, s);
   return rc;
+}
+
+extern "C" int ptv3_window_attn_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                    void* out, int64_t n, int64_t n_pad, int c, int heads, int patch,
+                                    float scale, const float* rpe_bias, int dtype, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(n_pad % patch == 0, "window_attn: n_pad=%lld is not a multiple of patch=%d (ragged windows: "
+               "ptv3_window_attn_varlen_fwd)", (long long)n_pad, patch);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn: bad dtype %d", dtype);
+  return window_attn_fwd_impl(qkv, win_order, win_inverse, nullptr, (int)(n_pad / patch), out, n, n_pad, c, heads,
+                              patch, scale, rpe_bias, dtype, 4.0 * n_pad * patch * c, (hipStream_t)stream);
+}
+
+extern "C" int ptv3_window_attn_varlen_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                           const int32_t* cu_seqlens, int num_windows, void* out, int64_t n,
+                                           int64_t n_pad, int c, int heads, int max_seqlen, float scale,
+                                           double sum_len_sq, int dtype, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_varlen: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(max_seqlen >= 1 && max_seqlen <= 16384, "window_attn_varlen: max_seqlen %d outside [1,16384]", max_seqlen);
+  PTV3_REQUIRE(cu_seqlens != nullptr && num_windows >= 1, "window_attn_varlen: cu_seqlens with >= 1 window required");
+  PTV3_REQUIRE(n_pad <= (int64_t)num_windows * max_seqlen && n_pad >= num_windows,
+               "window_attn_varlen: n_pad=%lld cannot be split into %d windows of 1..%d slots", (long long)n_pad,
+               num_windows, max_seqlen);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_varlen: bad dtype %d", dtype);
+  const double flops = 4.0 * (sum_len_sq > 0 ? sum_len_sq : (double)n_pad * max_seqlen) * c;
+  return window_attn_fwd_impl(qkv, win_order, win_inverse, cu_seqlens, num_windows, out, n, n_pad, c, heads,
+                              max_seqlen, scale, nullptr, dtype, flops, (hipStream_t)stream);
 }
 
 extern "C" int ptv3_window_attn_rpe_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,

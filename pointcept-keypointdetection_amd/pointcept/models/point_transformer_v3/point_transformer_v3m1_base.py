@@ -6,9 +6,12 @@ pointcept/models/point_transformer_v3/point_transformer_v3m1_base.py: same class
 PointTransformerV3), same constructor keywords and defaults (:520-552), same module tree and
 state_dict keys (:595-697).  All arithmetic runs in libptv3_hip.so (include/ptv3_hip.h):
 serialization + radix argsort, pad plan, fused window attention, implicit-GEMM linear / sparse conv,
-LayerNorm, folded BatchNorm, segmented pooling.  `enable_flash` is accepted for config
-compatibility: both settings run the same fused window kernel; the flag only selects the reference's
-patch-size rule (:173-176) so results match the reference for either value.
+LayerNorm, folded BatchNorm, segmented pooling.  Both `enable_flash` settings run the same fused window
+kernel.  enable_flash=False: the patch shrinks to the smallest scene (:173-176), every window has K slots.
+enable_flash=True: K is fixed, a scene with fewer than K points is ONE short window (:131-133) and the
+windows go through the ragged form of the kernel (ptv3_window_attn_varlen_fwd: the semantics of the
+flash_attn_varlen_qkvpacked_func call at :207-215, computed in the model's dtype; attention dropout of
+that call (`attn_drop` > 0 in training) is not implemented and raises).
 """
 import math
 from functools import partial
@@ -120,6 +123,16 @@ class SerializedAttention(PointModule):
             self.patch_size = min(min(counts), self.patch_size_max)
         return self.patch_size
 
+    def window_cu(self, point):
+        """cu_seqlens of the pad plan when some window is short (a scene with fewer points than the fixed patch of
+        enable_flash=True, :131-133), else None: all windows then have K slots."""
+        if not self.enable_flash:
+            return None
+        host = point.offset_host()
+        if all(b - a >= self.patch_size for a, b in zip([0] + host[:-1], host)):
+            return None
+        return self.get_padding_and_inverse(point)[2]
+
     def attention_core(self, point, qkv):
         """gather -> softmax(QK^T)V -> scatter (:188-216) in one kernel."""
         K = self.resolve_patch_size(point)
@@ -139,7 +152,10 @@ class SerializedAttention(PointModule):
             p_drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else float(self.attn_drop)
             if p_drop > 0.0:  # the reference drops attention probabilities (:203, :211); no such kernel here yet
                 raise NotImplementedError("SerializedAttention: attn_drop > 0 has no training kernel on the HIP path")
-            return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale)
+            return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, self.window_cu(point))
+        cu = self.window_cu(point)
+        if cu is not None:
+            return ops.window_attention_varlen(qkv, wo, wi, cu, self.num_heads, K, self.scale)
         return ops.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, rpe_bias=bias)
 
     def forward(self, point):
@@ -302,7 +318,8 @@ class Block(PointModule):
         mask1 = self._drop_mask(feat)
         mask2 = self._drop_mask(feat)
         out = A.block(feat, conv_feat, params, spt.neighbors(3, self.cpe[0].indice_key), spt.row_order, wo, wi,
-                      self.attn.num_heads, K, self.attn.scale, mask1, mask2, self.cpe[2].eps)
+                      self.attn.num_heads, K, self.attn.scale, mask1, mask2, self.cpe[2].eps,
+                      self.attn.window_cu(point))
         point.feat = out
         point.sparse_conv_feat = spt.replace_feature(out)
         return point

@@ -63,7 +63,9 @@ class LinearFn(Function):
             wt = ctx.wt if ctx.wt is not None else _pad_cols(ctx.w[:, :ctx.cin].t().contiguous(), gran)
             dx = ops.gemm(dyp, wt)
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy, xp)[:, :ctx.cin].to(weight.dtype)
+            # the kernel wants cout in multiples of 4 (a class count like 13 or 19 is not): zero columns, dropped again
+            dy4 = _pad_cols(dy, 4)
+            dw = ops.gemm_tn(dy4, xp)[:dy.shape[1], :ctx.cin].to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_reduce(dy)
         return dx, dw, db
@@ -214,19 +216,19 @@ class WindowAttentionFn(Function):
     """softmax(scale q k^T) v per serialized window, gather / scatter fused (:188-216)."""
 
     @staticmethod
-    def forward(ctx, qkv, win_order, win_inverse, heads, patch, scale):
+    def forward(ctx, qkv, win_order, win_inverse, heads, patch, scale, cu=None):
         qkv = qkv.contiguous()
-        out = ops.window_attention(qkv, win_order, win_inverse, heads, patch, scale)
-        ctx.save_for_backward(qkv, out, win_order, win_inverse)
+        out = ops.window_attention_any(qkv, win_order, win_inverse, heads, patch, scale, cu)
+        ctx.save_for_backward(qkv, out, win_order, win_inverse, cu)
         ctx.cfg = (heads, patch, scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, win_order, win_inverse = ctx.saved_tensors
+        qkv, out, win_order, win_inverse, cu = ctx.saved_tensors
         heads, patch, scale = ctx.cfg
-        return (ops.window_attention_bwd(qkv, out, dout.contiguous(), win_order, win_inverse, heads, patch, scale),
-                None, None, None, None, None)
+        return (ops.window_attention_bwd(qkv, out, dout.contiguous(), win_order, win_inverse, heads, patch, scale, cu),
+                None, None, None, None, None, None)
 
 
 class SegmentMaxFn(Function):
@@ -286,8 +288,8 @@ def activation(x, act):
     return ActFn.apply(x, act)
 
 
-def window_attention(qkv, win_order, win_inverse, heads, patch, scale):
-    return WindowAttentionFn.apply(qkv, win_order, win_inverse, heads, patch, scale)
+def window_attention(qkv, win_order, win_inverse, heads, patch, scale, cu=None):
+    return WindowAttentionFn.apply(qkv, win_order, win_inverse, heads, patch, scale, cu)
 
 
 def segment_max(feat, order0, seg_start, n_out):
@@ -327,7 +329,7 @@ class BlockFn(Function):
     @staticmethod
     def forward(ctx, feat, conv_feat, conv_w, conv_b, lin_w, lin_b, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b,
                 proj_w, proj_b, n2_g, n2_b, fc1_w, fc1_b, fc2_w, fc2_b, nbr, row_order, wo, wi, heads, patch, scale,
-                mask1, mask2, eps):
+                mask1, mask2, eps, cu=None):
         dt = feat.dtype
         feat = feat.contiguous()
         same = conv_feat is None
@@ -342,7 +344,7 @@ class BlockFn(Function):
         f1 = ops.layernorm(c2, f32(ln0_g), f32(ln0_b), eps, res=feat)
         t3 = ops.layernorm(f1, f32(n1_g), f32(n1_b), eps)
         qkv = _lin_fwd(t3, w_qkv[0], qkv_b)
-        a = ops.window_attention(qkv, wo, wi, heads, patch, scale)
+        a = ops.window_attention_any(qkv, wo, wi, heads, patch, scale, cu)
         p = _lin_fwd(a, w_proj[0], proj_b)
         f2 = f1 + (p if mask1 is None else p * mask1)
         t5 = ops.layernorm(f2, f32(n2_g), f32(n2_b), eps)
@@ -351,7 +353,7 @@ class BlockFn(Function):
         m = _lin_fwd(h, w_fc2[0], fc2_b)
         out = f2 + (m if mask2 is None else m * mask2)
         ctx.save_for_backward(xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2,
-                              conv_w, ln0_g, n1_g, n2_g)
+                              conv_w, ln0_g, n1_g, n2_g, cu)
         ctx.cast = (w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2)
         ctx.cfg = (heads, patch, scale, eps, same)
         return out
@@ -359,7 +361,7 @@ class BlockFn(Function):
     @staticmethod
     def backward(ctx, dout):
         (xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2, conv_w, ln0_g, n1_g,
-         n2_g) = ctx.saved_tensors
+         n2_g, cu) = ctx.saved_tensors
         w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2 = ctx.cast
         heads, patch, scale, eps, same = ctx.cfg
         dt = dout.dtype
@@ -377,7 +379,7 @@ class BlockFn(Function):
         # ---- attention branch
         dp = df2 if mask1 is None else df2 * mask1
         da, dW_proj, db_proj = _lin_bwd(dp, a, w_proj, gran)
-        dqkv = ops.window_attention_bwd(qkv, a, da.contiguous(), wo, wi, heads, patch, scale)
+        dqkv = ops.window_attention_bwd(qkv, a, da.contiguous(), wo, wi, heads, patch, scale, cu)
         dt3, dW_qkv, db_qkv = _lin_bwd(dqkv, t3, w_qkv, gran)
         dx, dg1, db1 = ops.layernorm_bwd(f1, dt3, f32(n1_g), eps)
         df1 = df2 + dx
@@ -396,8 +398,9 @@ class BlockFn(Function):
         c = lambda t: t.to(pd)  # noqa: E731
         return (dfeat, None if same else dxin, c(dW_conv), c(db_conv), c(dW_lin), c(db_lin), c(dg0), c(db0), c(dg1),
                 c(db1), c(dW_qkv), c(db_qkv), c(dW_proj), c(db_proj), c(dg2), c(db2), c(dW_fc1), c(db_fc1), c(dW_fc2),
-                c(db_fc2), None, None, None, None, None, None, None, None, None, None)
+                c(db_fc2), None, None, None, None, None, None, None, None, None, None, None)
 
 
-def block(feat, conv_feat, blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps):
-    return BlockFn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps)
+def block(feat, conv_feat, blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps, cu=None):
+    return BlockFn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps,
+                         cu)

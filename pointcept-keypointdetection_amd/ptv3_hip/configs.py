@@ -1,0 +1,37 @@
+"""Model configurations of the path as plain dicts (data only): the fork's keypoint-offset config and the small
+plumbing configs the tests / smoke run use.  Keys are the constructor keywords of "PT-v3m1" / "PT-v3m2"."""
+ORDERS = ["z", "z-trans", "hilbert", "hilbert-trans"]
+
+# plumbing-size "PT-v3m1"
+TINY_CFG = dict(
+    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
+    enc_depths=(1, 1, 1, 2, 1), enc_channels=(16, 16, 32, 32, 64), enc_num_head=(1, 1, 2, 2, 4),
+    enc_patch_size=(64,) * 5, dec_depths=(1, 1, 1, 1), dec_channels=(16, 16, 32, 32),
+    dec_num_head=(1, 1, 2, 2), dec_patch_size=(64,) * 4, mlp_ratio=4, qkv_bias=True,
+    drop_path=0.3, shuffle_orders=True, pre_norm=True, enable_rpe=False, enable_flash=False,
+    upcast_attention=False, upcast_softmax=False,
+)
+
+# the fork's config (configs/my_dataset/offset_keypoint_ptv3.py:11-46)
+FORK_CFG = dict(
+    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
+    enc_depths=(2, 2, 2, 6, 2), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+    enc_patch_size=(1024,) * 5, dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
+    dec_num_head=(4, 4, 8, 16), dec_patch_size=(1024,) * 4, mlp_ratio=4, qkv_bias=True, qk_scale=None,
+    attn_drop=0.0, proj_drop=0.0, drop_path=0.3, shuffle_orders=True, pre_norm=True, enable_rpe=False,
+    enable_flash=False, upcast_attention=False, upcast_softmax=False,
+)
+
+# the upstream PTv3 semantic-segmentation backbone (configs/scannet/semseg-pt-v3m1-0-base.py:14-44,
+# configs/nuscenes/semseg-pt-v3m1-0-base.py): same widths as the fork, enable_flash=True, 1024-point patches
+SEMSEG_CFG = dict(FORK_CFG, enable_flash=True)
+
+# "PT-v3m2" (point_transformer_v3m2_sonata.py) plumbing-size config: GridPooling, LayerScale, LayerNorm stem
+TINY_M2_CFG = dict(
+    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
+    enc_depths=(1, 1, 1, 2, 1), enc_channels=(16, 16, 32, 32, 64), enc_num_head=(1, 1, 2, 2, 4),
+    enc_patch_size=(64,) * 5, dec_depths=(1, 1, 1, 1), dec_channels=(16, 16, 32, 32),
+    dec_num_head=(1, 1, 2, 2), dec_patch_size=(64,) * 4, mlp_ratio=4, qkv_bias=True,
+    drop_path=0.3, layer_scale=0.5, shuffle_orders=True, pre_norm=True, enable_rpe=False, enable_flash=False,
+    upcast_attention=False, upcast_softmax=False,
+)

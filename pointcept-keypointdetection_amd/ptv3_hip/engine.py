@@ -26,7 +26,7 @@ class ForwardIO(ctypes.Structure):
                 ("out_head", c_void_p), ("stage_points_host", POINTER(c_int64)), ("depth_out", POINTER(c_int32)),
                 ("batch_out", c_void_p), ("inputs_resident", c_int32), ("overlap_calls", c_int32),
                 ("raw_feat", c_void_p), ("raw_feat_channels", c_int32), ("raw_feat_dtype", c_int32),
-                ("arena_n", c_int64), ("arena_b", c_int32)]
+                ("arena_n", c_int64), ("arena_b", c_int32), ("executor", c_void_p)]
 
 
 def declare(dll):
@@ -35,6 +35,32 @@ def declare(dll):
     dll.ptv3_forward.restype = ctypes.c_int
     dll.ptv3_forward.argtypes = [POINTER(ModelDesc), POINTER(c_void_p), ctypes.c_int, POINTER(ForwardIO), c_void_p,
                                  ctypes.c_size_t, c_void_p]
+
+
+class Executor:
+    """Handle of one native executor (ptv3_executor_create): the internal streams, events and call parity of
+    ptv3_forward.  One per (backbone, device), so two models - or one model replicated on two devices - never share
+    streams or the alternating arena halves."""
+
+    def __init__(self):
+        self._dll = lib.load()
+        self.handle = self._dll.ptv3_executor_create()
+        if not self.handle:
+            raise RuntimeError("ptv3_executor_create failed")
+
+    def __deepcopy__(self, memo):   # copy.deepcopy(model): the copy gets an executor of its own
+        return Executor()
+
+    def __reduce__(self):
+        return (Executor, ())
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._dll.ptv3_executor_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 def _bn(bn):
@@ -254,27 +280,36 @@ def forward(backbone, point, dtype, head=None):
         # call's head, queued behind that call's completion wait) - which would then scribble over this call's
         # codes / orders while the geometry kernels are reading them.  Hence a persistent ring of three generations
         # per shape: call i's tensors stay valid until call i+3 is issued.
-        ring = backbone.__dict__.setdefault("_engine_out_ring", {})
-        rkey = (n, k, desc.dec_channels[0], dtype, desc.head_out if head is not None else 0, dev)
-        slot = ring.get(rkey)
-        if slot is None:
+        # The ring is sized by CAPACITY (grow-only, x1.25 like the arena), not by this call's n: real datasets have a
+        # different point count in almost every batch, and a ring per distinct n would grow without bound and drain the
+        # device on nearly every call.  A call receives views [:n] of its generation's flat buffers.  The returned
+        # point.feat / serialized_* tensors are such views: they are overwritten three calls later.
+        ring = backbone.__dict__.get("_engine_out_ring")
+        c_out, c_head = desc.dec_channels[0], (desc.head_out if head is not None else 0)
+        rkey = (k, c_out, dtype, c_head, dev)
+        if ring is None or ring["key"] != rkey or ring["cap"] < n:
+            cap_n = max(n, int((ring["cap"] if ring is not None and ring["key"] == rkey else 0) * 1.25))
+
             def gen():
-                return dict(code=torch.empty((k, n), dtype=torch.int64, device=dev),
-                            order=torch.empty((k, n), dtype=torch.int64, device=dev),
-                            inverse=torch.empty((k, n), dtype=torch.int64, device=dev),
-                            batch=torch.empty(n, dtype=torch.int64, device=dev),
-                            out_feat=torch.empty((n, desc.dec_channels[0]), dtype=dtype, device=dev),
-                            out_head=(torch.empty((n, desc.head_out), dtype=torch.float32, device=dev)
+                return dict(code=torch.empty(k * cap_n, dtype=torch.int64, device=dev),
+                            order=torch.empty(k * cap_n, dtype=torch.int64, device=dev),
+                            inverse=torch.empty(k * cap_n, dtype=torch.int64, device=dev),
+                            batch=torch.empty(cap_n, dtype=torch.int64, device=dev),
+                            out_feat=torch.empty(cap_n * c_out, dtype=dtype, device=dev),
+                            out_head=(torch.empty(cap_n * c_head, dtype=torch.float32, device=dev)
                                       if head is not None else None))
             torch.cuda.synchronize(dev)        # nothing pending anywhere on the blocks these allocations receive
-            slot = ring[rkey] = {"i": 0, "bufs": [gen() for _ in range(3)]}
+            backbone.__dict__["_engine_out_ring"] = None   # release the old generations before allocating
+            ring = {"key": rkey, "cap": cap_n, "i": 0, "bufs": [gen() for _ in range(3)]}
+            backbone.__dict__["_engine_out_ring"] = ring
             torch.cuda.synchronize(dev)
-        cur = slot["bufs"][slot["i"] % 3]
-        slot["i"] += 1
-        code, order, inverse = cur["code"], cur["order"], cur["inverse"]
-        out_feat, out_head = cur["out_feat"], cur["out_head"]
+        cur = ring["bufs"][ring["i"] % 3]
+        ring["i"] += 1
+        code, order, inverse = (cur[q][:k * n].view(k, n) for q in ("code", "order", "inverse"))
+        out_feat = cur["out_feat"][:n * c_out].view(n, c_out)
+        out_head = cur["out_head"][:n * c_head].view(n, c_head) if head is not None else None
         if derive_batch:
-            batch = cur["batch"]
+            batch = cur["batch"][:n]
             point["batch"] = batch
         # inputs that had to be converted just now were produced on the caller's stream, which the executor's
         # streams do not wait for in these modes: settle them, and keep them alive for the ring generation
@@ -303,8 +338,13 @@ def forward(backbone, point, dtype, head=None):
         arena = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize(dev)
         backbone.__dict__["_engine_arena"], backbone.__dict__["_engine_arena_cap"] = arena, cap
+    execs = backbone.__dict__.setdefault("_engine_exec", {})
+    if dev not in execs:
+        with torch.cuda.device(dev):   # an executor binds to the device that is current when it is created
+            execs[dev] = Executor()
     stage_pts = (c_int64 * 8)()
     io = ForwardIO()
+    io.executor = execs[dev].handle
     io.grid_coord, io.coord_is_i64 = gc.data_ptr(), int(gc.dtype == torch.int64)
     io.feat, io.offset = feat.data_ptr(), offset.data_ptr()
     io.overlap_calls = int(overlap)

@@ -24,8 +24,10 @@ SIGNATURES = {
     "ptv3_argsort_i64": (c_int, [P, c_int, c_int64, c_int, P, P, P, c_size_t, P]),
     "ptv3_pad_plan": (c_int, [P, c_int, c_int64, c_int64, c_int, P, P, P, P]),
     "ptv3_window_maps": (c_int, [P, P, P, P, c_int64, c_int64, P, P, P]),
-    "ptv3_window_plan": (c_int, [P, P, P, c_int, c_int, c_int64, c_int64, c_int, P, P, P]),
+    "ptv3_window_plan": (c_int, [P, P, P, c_int, c_int, c_int64, c_int64, c_int, P, P, P, P]),
     "ptv3_window_attn_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, P, c_int, P]),
+    "ptv3_window_attn_varlen_fwd": (c_int, [P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
+                                            c_double, c_int, P]),
     "ptv3_window_attn_rpe_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, P, P, c_int,
                                          c_int, P]),
     "ptv3_subm_table_slots": (c_int64, [c_int64]),
@@ -50,6 +52,8 @@ SIGNATURES = {
                                  P, P, P, c_int, P]),
     "ptv3_forward_workspace_bytes": (c_size_t, [P, c_int64, c_int]),
     "ptv3_forward": (c_int, [P, P, c_int, P, P, c_size_t, P]),
+    "ptv3_executor_create": (c_void_p, []),
+    "ptv3_executor_destroy": (c_int, [P]),
     "ptv3_gemm_tn_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "ptv3_gemm_tn": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "ptv3_col_reduce_workspace_bytes": (c_size_t, [c_int64, c_int]),
@@ -62,10 +66,13 @@ SIGNATURES = {
     "ptv3_window_attn_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
     "ptv3_window_attn_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_int, P,
                                      c_size_t, P]),
+    "ptv3_window_attn_varlen_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
+                                            c_int, P, c_size_t, P]),
     "ptv3_adamw_entry_bytes": (c_size_t, []),
     "ptv3_adamw_chunk": (c_int, []),
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
     "ptv3_adamw_fill_shadow": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
+    "ptv3_adamw_fill_step_lag": (c_int, [P, c_int64]),
     "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P]),
     "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P]),
     "ptv3_grid_hash": (c_int, [P, c_int64, c_double, c_int, P, P, P, P]),

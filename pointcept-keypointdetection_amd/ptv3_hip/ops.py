@@ -78,16 +78,30 @@ def argsort_codes(code, end_bit):
     return order, inverse
 
 
+def plan_sizes(offset_host, patch):
+    """(n_pad, windows, ragged, sum of len^2) of the pad plan (v3m1_base.py:114-170): a scene longer than `patch` is
+    padded to a multiple of it, a shorter one stays ONE short window (ragged; only with enable_flash=True)."""
+    prev, n_pad, nwin, ragged, sq = 0, 0, 0, False, 0
+    for o in offset_host:
+        cnt = o - prev
+        prev = o
+        w = (cnt + patch - 1) // patch
+        nwin += w
+        if cnt < patch:
+            ragged = True
+            n_pad += cnt
+            sq += cnt * cnt
+        else:
+            n_pad += w * patch
+            sq += w * patch * patch
+    return n_pad, nwin, ragged, sq
+
+
 def pad_plan(offset, offset_host, patch):
     """pad, unpad, cu_seqlens of SerializedAttention.get_padding_and_inverse (v3m1_base.py:114-170)."""
     _chk(offset, "offset", torch.int64, 1)
-    prev, n_pad = 0, 0
-    for o in offset_host:
-        cnt = o - prev
-        n_pad += (cnt + patch - 1) // patch * patch if cnt > patch else cnt
-        prev = o
+    n_pad, nwin, _, _ = plan_sizes(offset_host, patch)
     n = int(offset_host[-1])
-    nwin = sum((((o - p) + patch - 1) // patch) for p, o in zip([0] + list(offset_host[:-1]), offset_host))
     pad = torch.empty(n_pad, dtype=torch.int64, device=offset.device)
     unpad = torch.empty(n, dtype=torch.int64, device=offset.device)
     cu = torch.empty(nwin + 1, dtype=torch.int32, device=offset.device)
@@ -107,22 +121,19 @@ def window_maps(order, inverse, pad, unpad):
     return wo, wi
 
 
-def window_plan(order, inverse, offset, offset_host, patch):
-    """(win_order (k, n_pad), win_inverse (k, n)) int32 for all k orders in one launch."""
+def window_plan(order, inverse, offset, offset_host, patch, with_cu=False):
+    """(win_order (k, n_pad), win_inverse (k, n)) int32 for all k orders in one launch [+ cu_seqlens (windows+1)]."""
     _chk(order, "order", torch.int64, 2)
     _chk(inverse, "inverse", torch.int64, 2)
     _chk(offset, "offset", torch.int64, 1)
     k, n = order.shape
-    prev, n_pad = 0, 0
-    for o in offset_host:
-        cnt = o - prev
-        n_pad += (cnt + patch - 1) // patch * patch if cnt > patch else cnt
-        prev = o
+    n_pad, nwin, _, _ = plan_sizes(offset_host, patch)
     wo = torch.empty((k, n_pad), dtype=torch.int32, device=order.device)
     wi = torch.empty((k, n), dtype=torch.int32, device=order.device)
+    cu = torch.empty(nwin + 1, dtype=torch.int32, device=order.device) if with_cu else None
     lib.check(lib.ptv3_window_plan(_p(order), _p(inverse), _p(offset), len(offset_host), k, n, n_pad, int(patch),
-                                   _p(wo), _p(wi), _stream()), "ptv3_window_plan")
-    return wo, wi
+                                   _p(wo), _p(wi), _p(cu), _stream()), "ptv3_window_plan")
+    return (wo, wi, cu) if with_cu else (wo, wi)
 
 
 def window_attention(qkv, win_order, win_inverse, heads, patch, scale, rpe_bias=None):
@@ -143,6 +154,32 @@ def window_attention(qkv, win_order, win_inverse, heads, patch, scale, rpe_bias=
                                        int(patch), float(scale), _p(rpe_bias), _dt(qkv), _stream()),
               "ptv3_window_attn_fwd")
     return out
+
+
+def window_attention_varlen(qkv, win_order, win_inverse, cu_seqlens, heads, max_seqlen, scale, sum_len_sq=0.0):
+    """The enable_flash=True call site (v3m1_base.py:207-215): flash_attn_varlen_qkvpacked_func semantics over ragged
+    windows [cu_seqlens[w], cu_seqlens[w+1]) of at most max_seqlen padded slots, gather / scatter fused."""
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    _chk(cu_seqlens, "cu_seqlens", torch.int32, 1)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    if win_inverse.shape[0] != n or c * 3 != c3 or cu_seqlens.numel() < 2:
+        raise RuntimeError("window_attention_varlen: shape mismatch")
+    out = torch.empty((n, c), dtype=qkv.dtype, device=qkv.device)
+    lib.check(lib.ptv3_window_attn_varlen_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(cu_seqlens),
+                                              cu_seqlens.numel() - 1, _p(out), n, win_order.shape[0], c, int(heads),
+                                              int(max_seqlen), float(scale), float(sum_len_sq), _dt(qkv), _stream()),
+              "ptv3_window_attn_varlen_fwd")
+    return out
+
+
+def window_attention_any(qkv, win_order, win_inverse, heads, patch, scale, cu_seqlens=None, sum_len_sq=0.0):
+    """Uniform windows (cu_seqlens None) or ragged ones (the pad plan's cu_seqlens)."""
+    if cu_seqlens is None:
+        return window_attention(qkv, win_order, win_inverse, heads, patch, scale)
+    return window_attention_varlen(qkv, win_order, win_inverse, cu_seqlens, heads, patch, scale, sum_len_sq)
 
 
 def window_attention_rpe(qkv, win_order, win_inverse, heads, patch, scale, grid_coord, rpe_table, pos_bnd):
@@ -536,8 +573,9 @@ def segment_sum(dy, order0, seg_start, n_out):
     return out
 
 
-def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, scale):
+def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, scale, cu_seqlens=None):
     _chk(qkv, "qkv", _F, 2)
+    _chk(cu_seqlens, "cu_seqlens", torch.int32, 1)
     _chk(out, "out", qkv.dtype, 2)
     _chk(dout, "dout", qkv.dtype, 2)
     _chk(win_order, "win_order", torch.int32, 1)
@@ -550,6 +588,12 @@ def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, s
     dqkv = torch.empty_like(qkv)
     nb = lib.ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, int(heads), _dt(qkv))
     ws = _ws(nb, qkv.device)
+    if cu_seqlens is not None:
+        lib.check(lib.ptv3_window_attn_varlen_bwd(_p(qkv), _p(out), _p(dout), _p(win_order), _p(win_inverse),
+                                                  _p(cu_seqlens), cu_seqlens.numel() - 1, _p(dqkv), n, n_pad, c,
+                                                  int(heads), int(patch), float(scale), _dt(qkv), _p(ws), nb,
+                                                  _stream()), "ptv3_window_attn_varlen_bwd")
+        return dqkv
     lib.check(lib.ptv3_window_attn_bwd(_p(qkv), _p(out), _p(dout), _p(win_order), _p(win_inverse), _p(dqkv), n, n_pad,
                                        c, int(heads), int(patch), float(scale), _dt(qkv), _p(ws), nb, _stream()),
               "ptv3_window_attn_bwd")

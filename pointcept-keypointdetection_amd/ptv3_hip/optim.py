@@ -48,7 +48,12 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = None
         self._nt = self._nb = 0
         self._partial = None
+        # Step accounting compatible with torch.optim.AdamW checkpoints: state[p]["step"] (CPU float tensor, as torch
+        # keeps it) is authoritative while p is NOT in the device table; for the tensors in the table the count is
+        # self._steps - lag (one launch argument + a per-entry constant instead of 495 host-side increments per step)
+        # and is written back whenever the table is rebuilt or a state_dict is taken.
         self._steps = 0
+        self._active = []   # (param, lag) of the current device table
 
     def _entries(self):
         out = []
@@ -64,6 +69,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdamW: parameters and gradients must be contiguous")
                 st = self.state[p]
                 if not st:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
                 out.append((p, st, gi))
@@ -84,7 +90,11 @@ class FusedAdamW(torch.optim.Optimizer):
                     for (p, _, gi), sh in zip(ent, shadows))
         if key == self._key:
             return
+        self._sync_steps()   # tensors leaving the table keep their own count in state["step"]
         esz, chunk = lib.ptv3_adamw_entry_bytes(), lib.ptv3_adamw_chunk()
+        # the launch's step argument is the largest per-tensor count + 1; everybody else lags behind it
+        self._steps = max([int(st["step"].item()) if "step" in st else 0 for _, st, _ in ent] or [0])
+        active = []
         host = ctypes.create_string_buffer(max(1, esz * len(ent)))
         base = ctypes.addressof(host)
         blocks = 0
@@ -92,6 +102,10 @@ class FusedAdamW(torch.optim.Optimizer):
             lib.check(lib.ptv3_adamw_fill_entry(base + i * esz, p.data_ptr(), p.grad.data_ptr(),
                                                 st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi,
                                                 blocks), "ptv3_adamw_fill_entry")
+            own = int(st["step"].item()) if "step" in st else 0
+            active.append((p, self._steps - own))
+            if self._steps != own:
+                lib.check(lib.ptv3_adamw_fill_step_lag(base + i * esz, self._steps - own), "ptv3_adamw_fill_step_lag")
             sh = shadows[i]
             if sh is not None:
                 rows, cols, kvol = sh["dims"]
@@ -102,7 +116,27 @@ class FusedAdamW(torch.optim.Optimizer):
         dev = ent[0][0].device if ent else torch.device("cuda")
         self._table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
         self._partial = torch.empty(max(blocks, 1), dtype=torch.float32, device=dev)
-        self._nt, self._nb, self._key = len(ent), blocks, key
+        self._nt, self._nb, self._key, self._active = len(ent), blocks, key, active
+
+    def _sync_steps(self):
+        """write the step counts of the tensors in the device table back into state[p]["step"]"""
+        for p, lag in self._active:
+            st = self.state[p]
+            st["step"] = torch.tensor(float(self._steps - lag), dtype=torch.float32)
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Accepts checkpoints of this class and of torch.optim.AdamW (exp_avg / exp_avg_sq / per-parameter step)."""
+        super().load_state_dict(state_dict)
+        for st in self.state.values():
+            if "step" in st and torch.is_tensor(st["step"]):
+                st["step"] = st["step"].detach().to("cpu", torch.float32)
+            elif "step" in st:
+                st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+        self._key, self._active = None, []   # moments are new tensors: rebuild the device table, re-derive the lags
 
     @torch.no_grad()
     def zero_grad(self, set_to_none=False):
@@ -129,6 +163,15 @@ class FusedAdamW(torch.optim.Optimizer):
         lib.check(lib.ptv3_adamw_step(self._table.data_ptr(), self._nt, self._nb, lr, wd, ng, float(b1), float(b2),
                                       float(self.param_groups[0]["eps"]), self._steps, float(grad_scale), _stream()),
                   "ptv3_adamw_step")
+        # The kernel wrote the parameters through raw pointers: tell torch.  Every eval-side cache (folded BatchNorm,
+        # cast / permuted weights, the executor's packed table) is keyed on (data_ptr, _version); without the bump an
+        # evaluation between two training epochs would keep running on the weights of the first one.
+        updated = [p for p, _ in self._active]
+        torch._C._increment_version(updated)
+        for p in updated:   # the shadows were written by the kernel itself: still exact at the new version
+            sh = getattr(p, "_ptv3_shadow", None)
+            if sh is not None:
+                sh["version"] = p._version
         return loss
 
     @torch.no_grad()

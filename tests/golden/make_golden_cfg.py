@@ -1,31 +1,10 @@
-"""Configs shared by make_golden.py and the tests (data only)."""
-ORDERS = ["z", "z-trans", "hilbert", "hilbert-trans"]
+"""Configs shared by the make_golden*.py scripts and the tests: they live in the package (ptv3_hip/configs.py)."""
+import os
+import sys
 
-TINY_CFG = dict(
-    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
-    enc_depths=(1, 1, 1, 2, 1), enc_channels=(16, 16, 32, 32, 64), enc_num_head=(1, 1, 2, 2, 4),
-    enc_patch_size=(64,) * 5, dec_depths=(1, 1, 1, 1), dec_channels=(16, 16, 32, 32),
-    dec_num_head=(1, 1, 2, 2), dec_patch_size=(64,) * 4, mlp_ratio=4, qkv_bias=True,
-    drop_path=0.3, shuffle_orders=True, pre_norm=True, enable_rpe=False, enable_flash=False,
-    upcast_attention=False, upcast_softmax=False,
-)
+_PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                    "pointcept-keypointdetection_amd")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
 
-# the fork's config (configs/my_dataset/offset_keypoint_ptv3.py:11-46)
-FORK_CFG = dict(
-    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
-    enc_depths=(2, 2, 2, 6, 2), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
-    enc_patch_size=(1024,) * 5, dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
-    dec_num_head=(4, 4, 8, 16), dec_patch_size=(1024,) * 4, mlp_ratio=4, qkv_bias=True, qk_scale=None,
-    attn_drop=0.0, proj_drop=0.0, drop_path=0.3, shuffle_orders=True, pre_norm=True, enable_rpe=False,
-    enable_flash=False, upcast_attention=False, upcast_softmax=False,
-)
-
-# "PT-v3m2" (point_transformer_v3m2_sonata.py) plumbing-size config: GridPooling, LayerScale, LayerNorm stem
-TINY_M2_CFG = dict(
-    in_channels=4, order=ORDERS, stride=(2, 2, 2, 2),
-    enc_depths=(1, 1, 1, 2, 1), enc_channels=(16, 16, 32, 32, 64), enc_num_head=(1, 1, 2, 2, 4),
-    enc_patch_size=(64,) * 5, dec_depths=(1, 1, 1, 1), dec_channels=(16, 16, 32, 32),
-    dec_num_head=(1, 1, 2, 2), dec_patch_size=(64,) * 4, mlp_ratio=4, qkv_bias=True,
-    drop_path=0.3, layer_scale=0.5, shuffle_orders=True, pre_norm=True, enable_rpe=False, enable_flash=False,
-    upcast_attention=False, upcast_softmax=False,
-)
+from ptv3_hip.configs import ORDERS, TINY_CFG, FORK_CFG, SEMSEG_CFG, TINY_M2_CFG  # noqa: E402,F401

@@ -11,6 +11,9 @@ package objects are pre-registered and four tiny third-party stubs are installed
   spconv.pytorch.SparseConvTensor  plain container
   torch_scatter.segment_csr        -> torch.segment_reduce
   timm.layers.DropPath             identity in eval mode
+  flash_attn.flash_attn_varlen_qkvpacked_func -> oracle.ptv3.varlen_attention (our restatement of the
+                                   published function; returns its input dtype like the library does)
+  torch_cluster, peft              bare modules (imported by models/default.py, unused by DefaultSegmentorV2)
 """
 import importlib
 import os
@@ -111,6 +114,22 @@ def _install_stubs():
     timm.layers = tl
     sys.modules.update({"timm": timm, "timm.layers": tl})
 
+    fa = types.ModuleType("flash_attn")
+
+    def flash_attn_varlen_qkvpacked_func(qkv, cu_seqlens, max_seqlen, dropout_p=0.0, softmax_scale=None, **kw):
+        assert dropout_p == 0
+        T, three, H, D = qkv.shape
+        assert int((cu_seqlens[1:] - cu_seqlens[:-1]).max()) <= max_seqlen
+        out = oracle_ptv3.varlen_attention(qkv.float(), cu_seqlens, H, softmax_scale if softmax_scale is not None
+                                           else D ** -0.5)
+        return out.to(qkv.dtype)
+
+    fa.flash_attn_varlen_qkvpacked_func = flash_attn_varlen_qkvpacked_func
+    sys.modules["flash_attn"] = fa
+    for name in ("torch_cluster", "peft"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["peft"].LoraConfig = sys.modules["peft"].get_peft_model = None
+
 
 def _bare_pkg(name, path):
     m = types.ModuleType(name)
@@ -155,5 +174,8 @@ def load():
     ns.v3m1 = importlib.import_module("pointcept.models.point_transformer_v3.point_transformer_v3m1_base")
     ns.offset_head = importlib.import_module("pointcept.models.offset_keypoint_ptv3")
     ns.Point = ns.structure.Point
+    # models/default.py (DefaultSegmentorV2) and the reference's own losses package (plain torch, imported in place)
+    ns.losses = importlib.import_module("pointcept.models.losses")
+    ns.default = importlib.import_module("pointcept.models.default")
     _loaded["ns"] = ns
     return ns

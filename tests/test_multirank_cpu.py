@@ -43,3 +43,25 @@ def test_two_rank_sharding_gloo():
     assert c0 != c1                                              # ... of different data
     assert e0 == e1 == 2.0                                       # MAX over ranks of the timed region
     assert t0 == t1 == n0 + n1 == 2000                           # whole-job points
+
+
+def test_bench_self_launch_two_gloo_ranks(capfd, monkeypatch):
+    """`bench.py --gpus 2` with no launcher in the environment starts its own two ranks (spawned processes, tcp
+    rendezvous on 127.0.0.1 - the process model of the reference's engines/launch.py) before any GPU call.
+    --rehearse-launch swaps the GPU work for the surrounding machinery: sharding, barrier, MAX / SUM reductions,
+    the all-reduce probe; rank 0 prints the one JSON line."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.main(["--gpus", "2", "--rehearse-launch", "--scenes", "2", "--points", "400", "--mode", "train"])
+    assert rc == 0
+    lines = [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["rehearsal"] is True and rec["value"] is None
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2
+    assert rec["elapsed_max"] == 2.0 and rec["total_points"] == 4 * 400
+    assert rec["scene_seeds_rank0"] == bench.rank_scene_seeds(0, 2)
+    assert rec["allreduce_probe"]["ranks"] == 2 and rec["allreduce_probe"]["busbw_GBps"] > 0

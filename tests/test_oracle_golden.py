@@ -185,3 +185,74 @@ def test_training_oracle_matches_reference_autograd(golden_dir):
         assert err <= 1e-5 * max(ref.abs().max().item(), 1e-3 * gmax), (name, err)
     for name, b in orc.named_buffers():
         assert (b - torch.from_numpy(g["buf_" + name])).abs().max().item() < 1e-6, name
+
+
+# ------------------------------------------------------------------------------------------------
+# enable_flash=True (fixed patch, ragged windows) and DefaultSegmentorV2 vs the reference's own runs
+# (tests/golden/flash_seg.npz, written by tests/golden/make_golden_flash_seg.py)
+# ------------------------------------------------------------------------------------------------
+def test_flash_padplan_golden(golden_dir):
+    """get_padding_and_inverse with the patch FIXED (enable_flash=True): scenes shorter than K are one short window."""
+    g = _load(golden_dir, "flash_seg.npz")
+    ragged = 0
+    for i in range(int(g["fp_cases"])):
+        off, K = g[f"fp{i}_offset"], int(g[f"fp{i}_K"])
+        pad, unpad, cu = sfc.pad_plan(off, K)
+        assert np.array_equal(pad, g[f"fp{i}_pad"]), i
+        assert np.array_equal(unpad, g[f"fp{i}_unpad"]), i
+        assert np.array_equal(cu, g[f"fp{i}_cu"]), i
+        ragged += int((np.diff(cu) < K).any())
+    assert ragged >= 5   # the fixture really holds short windows
+
+
+def test_flash_attention_golden(golden_dir):
+    g = _load(golden_dir, "flash_seg.npz")
+    for i in range(int(g["fa_cases"])):
+        t = f"fa{i}_"
+        C, H, K, oi = [int(v) for v in g[t + "cfg"]]
+        off, gc = g[t + "offset"], g[t + "grid_coord"]
+        batch = np.repeat(np.arange(len(off)), np.diff(off, prepend=0))
+        _, order, inverse, _ = sfc.serialization(gc, batch, ORDERS)
+        pad, unpad, cu = sfc.pad_plan(off, K)
+        assert np.array_equal(cu, g[t + "cu"]), i
+        w = {k[len(t) + 2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(t + "w_")}
+        args = (torch.from_numpy(g[t + "feat"]), w["qkv.weight"], w["qkv.bias"], w["proj.weight"], w["proj.bias"],
+                torch.from_numpy(order[oi]), torch.from_numpy(inverse[oi]), torch.from_numpy(pad),
+                torch.from_numpy(unpad), torch.from_numpy(cu), H)
+        ref = torch.from_numpy(g[t + "out"])
+        # with the call site's own bf16 cast (:209) and the library's bf16 result: the reference run itself
+        assert (O.window_attention_flash(*args, bf16_io=True) - ref).abs().max().item() < 2e-6, i
+        # the exact-fp32 form (what the HIP fp32 mode computes) stays within bf16 rounding of it
+        exact = O.window_attention_flash(*args, bf16_io=False)
+        assert (exact - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item()), i
+
+
+def test_flash_model_golden(golden_dir):
+    g = _load(golden_dir, "flash_seg.npz")
+    sd = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fm_sd_")}
+    data = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("fm_in_")}
+    cfg = dict(TINY_CFG, enable_flash=True)
+    orc = O.OffsetKeypointOracle(cfg, sd)
+    orc.backbone.flash_bf16_io = True
+    torch.manual_seed(int(g["fm_shuffle_seed"]))
+    with torch.no_grad():
+        out = orc.forward(data)
+    tr = orc.backbone.trace
+    for k in [f"enc{s}" for s in range(5)] + [f"dec{s}" for s in range(4)]:
+        assert tr[k].shape == g["fm_tap_" + k].shape, k
+        assert np.abs(tr[k].numpy() - g["fm_tap_" + k]).max() < 5e-5, k
+    assert np.abs(out["pred"].numpy() - g["fm_pred"]).max() < 5e-5
+    assert abs(out["loss"].item() - float(g["fm_loss"])) < 1e-5
+
+
+def test_segmentor_golden(golden_dir):
+    """DefaultSegmentorV2 restatement vs the reference class + the reference's own CrossEntropyLoss."""
+    g = _load(golden_dir, "flash_seg.npz")
+    sd = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sg_sd_")}
+    data = {k[6:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sg_in_")}
+    orc = O.SegmentorOracle(TINY_CFG, sd)
+    torch.manual_seed(int(g["sg_shuffle_seed"]))
+    with torch.no_grad():
+        out = orc.forward(data)
+    assert np.abs(out["seg_logits"].numpy() - g["sg_seg_logits"]).max() < 2e-5
+    assert abs(out["loss"].item() - float(g["sg_loss"])) < 1e-5
