@@ -58,3 +58,29 @@ def interpolation_forward(inp, idx, weight):
     _lib().oracle_interpolation_forward(ctypes.c_int(n), ctypes.c_int(c), ctypes.c_int(k), _ptr(inp), _ptr(idx),
                                         _ptr(weight), _ptr(out))
     return out
+
+
+def grouping_backward(grad_out, idx, n):
+    """grad_in (n, c) of grouping_forward; idx must not hold -1 (the reference kernel would write out of bounds:
+    its Python wrapper routes -1 through an appended zero row, functions/grouping.py:41-63)."""
+    grad_out = np.ascontiguousarray(grad_out, dtype=np.float32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    assert (idx >= 0).all()
+    m, ns, c = grad_out.shape
+    grad_in = np.zeros((n, c), dtype=np.float32)
+    _lib().oracle_grouping_backward(ctypes.c_int(m), ctypes.c_int(ns), ctypes.c_int(c), _ptr(grad_out), _ptr(idx),
+                                    _ptr(grad_in))
+    return grad_in
+
+
+def interpolation_backward(grad_out, idx, weight, m):
+    grad_out = np.ascontiguousarray(grad_out, dtype=np.float32)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    assert (idx >= 0).all()
+    n, c = grad_out.shape
+    k = idx.shape[1]
+    grad_in = np.zeros((m, c), dtype=np.float32)
+    _lib().oracle_interpolation_backward(ctypes.c_int(n), ctypes.c_int(c), ctypes.c_int(k), _ptr(grad_out), _ptr(idx),
+                                         _ptr(weight), _ptr(grad_in))
+    return grad_in

@@ -77,3 +77,26 @@ void oracle_interpolation_forward(int n, int c, int k, const float* input, const
       output[index] += input[(int64_t)idx[ni * k + i] * c + c_idx] * weight[ni * k + i];
   }
 }
+
+/* grouping_backward_cuda_kernel, libs/pointops/src/grouping/grouping_cuda_kernel.cu:16-25: one atomicAdd per
+ * (m, nsample, c) element into grad_in[idx]; here the threads run in index order (the CUDA order is unspecified:
+ * fp32 sums agree with a GPU run up to the order of additions). */
+void oracle_grouping_backward(int m, int nsample, int c, const float* grad_out, const int* idx, float* grad_in) {
+  for (int64_t index = 0; index < (int64_t)m * nsample * c; ++index) {
+    int c_idx = index % c;
+    int ns = (index / c) % nsample;
+    int64_t mi = index / nsample / c;
+    grad_in[(int64_t)idx[mi * nsample + ns] * c + c_idx] += grad_out[index];
+  }
+}
+
+/* interpolation_backward_cuda_kernel, libs/pointops/src/interpolation/interpolation_cuda_kernel.cu:20-33 */
+void oracle_interpolation_backward(int n, int c, int k, const float* grad_out, const int* idx, const float* weight,
+                                   float* grad_in) {
+  for (int64_t index = 0; index < (int64_t)n * c; ++index) {
+    int c_idx = index % c;
+    int64_t ni = index / c;
+    for (int i = 0; i < k; i++)
+      grad_in[(int64_t)idx[ni * k + i] * c + c_idx] += grad_out[index] * weight[ni * k + i];
+  }
+}

@@ -212,6 +212,174 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Large-M tile: 128 points x BN (64 | 128) channels per 4-wave workgroup, every wave a (BM/WM) x (BN/WN) sub-tile
+// held as MI x NJ accumulator fragments (64 x 64 = 4 x 4 at BN = 128: one LDS fragment read per 2 matrix-core
+// steps instead of 1.25 reads per step in gemm_kernel above, whose 16 x 64 wave tile is bound by LDS bandwidth
+// at ~40 % of the matrix peak and measured ~10 %).  The two operand tiles are double-buffered in LDS with ONE
+// barrier per K step: tile t+1 (fetched into registers during step t-1) is written to the idle buffer at the top
+// of step t, the loads of tile t+2 are issued right after, then the fragments of tile t feed the matrix core.
+// LDS rows are 128 bytes (8 x 16-byte chunks, chunk c of row r at c ^ ((r >> 1) & 7): conflict-free ds_read_b128 /
+// ds_write_b128 without padding); the neighbour table of the tile's 128 points (kvol <= 27) sits in LDS, so the
+// gathered row addresses of a sparse convolution cost no dependent global load.  Same operands, epilogue and
+// results as gemm_kernel (fp32: bitwise, the accumulation order over K is the same).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int GB_BM = 128;
+constexpr int GB_THREADS = 256;
+constexpr int GB_MAX_KVOL = 27;
+
+template <typename T, int WM, int WN, int BN>
+__global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  constexpr int E = F::E;
+  constexpr int BK = 2 * F::KC;                 // 128 bytes of K per row and stage
+  constexpr int MI = GB_BM / (16 * WM);         // point fragments per wave
+  constexpr int NJ = BN / (16 * WN);            // channel fragments per wave
+  constexpr int X_LOADS = (GB_BM * 8) / GB_THREADS;  // 4
+  constexpr int W_LOADS = (BN * 8) / GB_THREADS;     // 2 | 4
+  static_assert(WM * WN == 4, "four waves");
+  extern __shared__ __attribute__((aligned(16))) char gb_smem[];
+  T* sX = reinterpret_cast<T*>(gb_smem);                         // [2][128][BK]
+  T* sW = sX + 2 * GB_BM * BK;                                   // [2][BN][BK]
+  int32_t* sNbr = reinterpret_cast<int32_t*>(sW + 2 * BN * BK);  // [128][kvol]
+
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wr = wave / WN, wc = wave % WN;
+  const unsigned ntm = gridDim.x;
+  // XCD-aware order: consecutive row tiles (neighbouring points: their gathers share rows in L2) on one XCD
+  const unsigned tile_m = xcd_remap(blockIdx.x, ntm);
+  const int64_t row0 = (int64_t)tile_m * GB_BM;
+  const int n0 = blockIdx.y * BN;
+  const int ktot = a.kvol * a.cin;
+  const int nsteps = (ktot + BK - 1) / BK;
+
+  // ---- staging map: thread -> chunk c = tid & 7 of rows (tid >> 3) + 32 u
+  const int c = tid & 7;
+  const int r0 = tid >> 3;
+  int64_t xrow[X_LOADS];   // dense: source row of x; conv: -1 marks rows beyond m
+#pragma unroll
+  for (int u = 0; u < X_LOADS; ++u) {
+    const int64_t r = row0 + r0 + 32 * u;
+    xrow[u] = r < a.m ? (a.row_order ? (int64_t)a.row_order[r] : r) : -1;
+  }
+  if (a.nbr) {
+    // neighbour rows of the tile's points -> LDS (row-major [point][kvol])
+    for (int e = tid; e < GB_BM * a.kvol; e += GB_THREADS) {
+      const int pr = e / a.kvol, d = e - pr * a.kvol;
+      const int64_t r = row0 + pr;
+      int32_t v = -1;
+      if (r < a.m) v = a.nbr[(a.row_order ? (int64_t)a.row_order[r] : r) * a.kvol + d];
+      sNbr[e] = v;
+    }
+    __syncthreads();
+  }
+
+  FR rx[X_LOADS], rw[W_LOADS];
+  auto issue = [&](int step) {
+    const int kk = step * BK + E * c;
+    const bool kin = kk < ktot;
+    int d = 0, cc = kk;
+    if (a.nbr) {
+      d = a.cin_shift >= 0 ? (kk >> a.cin_shift) : (kk / a.cin);
+      cc = kk - d * a.cin;
+    }
+#pragma unroll
+    for (int u = 0; u < X_LOADS; ++u) {
+      rx[u] = F::zero();
+      int64_t src = xrow[u];
+      if (a.nbr && kin) src = sNbr[(r0 + 32 * u) * a.kvol + d];
+      if (kin && src >= 0) rx[u] = *reinterpret_cast<const FR*>(x + src * a.cin + cc);
+    }
+#pragma unroll
+    for (int u = 0; u < W_LOADS; ++u) {
+      rw[u] = F::zero();
+      const int o = n0 + r0 + 32 * u;
+      if (kin && o < a.cout) rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < X_LOADS; ++u) {
+      const int r = r0 + 32 * u;
+      *reinterpret_cast<FR*>(sX + ((size_t)buf * GB_BM + r) * BK + E * (c ^ ((r >> 1) & 7))) = rx[u];
+    }
+#pragma unroll
+    for (int u = 0; u < W_LOADS; ++u) {
+      const int r = r0 + 32 * u;
+      *reinterpret_cast<FR*>(sW + ((size_t)buf * BN + r) * BK + E * (c ^ ((r >> 1) & 7))) = rw[u];
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int m = 0; m < MI; ++m)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  stash(0);
+  if (nsteps > 1) issue(1);
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+    if (step + 1 < nsteps) stash(buf ^ 1);      // tile step+1: its readers (step-1) are behind the last barrier
+    if (step + 2 < nsteps) issue(step + 2);
+    const T* bx = sX + (size_t)buf * GB_BM * BK;
+    const T* bw = sW + (size_t)buf * BN * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      FR xf[MI], wf[NJ];
+#pragma unroll
+      for (int m = 0; m < MI; ++m) {
+        const int r = (MI * wr + m) * 16 + li;
+        xf[m] = *reinterpret_cast<const FR*>(bx + (size_t)r * BK + E * ((4 * ks + g) ^ ((r >> 1) & 7)));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = (NJ * wc + j) * 16 + li;
+        wf[j] = *reinterpret_cast<const FR*>(bw + (size_t)r * BK + E * ((4 * ks + g) ^ ((r >> 1) & 7)));
+      }
+#pragma unroll
+      for (int m = 0; m < MI; ++m)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[m][j] = F::mma(wf[j], xf[m], acc[m][j]);  // D[channel 4g+r][point li]
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns point (16 (MI wr + m) + li), channels n0 + 16 (NJ wc + j) + 4g .. +3
+#pragma unroll
+  for (int m = 0; m < MI; ++m) {
+    const int64_t prow = row0 + (MI * wr + m) * 16 + li;
+    if (prow >= a.m) continue;
+    const int64_t orow = a.row_order ? (int64_t)a.row_order[prow] : prow;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int ch0 = n0 + (NJ * wc + j) * 16 + 4 * g;
+      if (ch0 >= a.cout) continue;
+      float v[4] = {acc[m][j][0], acc[m][j][1], acc[m][j][2], acc[m][j][3]};
+      epilogue_store<T>(a, orow, ch0, v);
+    }
+  }
+}
+
+// the large tile pays once its grid fills the chip; below that the 64-point tile (+ split-K) has more workgroups
+static bool use_big_tile(int64_t m, int cin, int cout, int kvol, int dtype, int* bn_out) {
+  const char* env = getenv("PTV3_GEMM_BIG");  // 0 off, 1 policy (default), 2 force; read per call so tests can switch
+  const int mode = env ? atoi(env) : 1;
+  if (mode == 0 || kvol > GB_MAX_KVOL || cout < 64) return false;
+  const int bn = cout >= 128 ? 128 : 64;
+  *bn_out = bn;
+  const int64_t tiles = cdiv(m, GB_BM) * cdiv(cout, bn);
+  const int64_t ktot = (int64_t)kvol * cin;
+  if (mode == 2) return true;
+  return tiles >= 256 && ktot >= 64 * (dtype == PTV3_F32 ? 1 : 2);
+}
+
 // sums the split-K slabs in slab order and applies the epilogue: one thread per (row, 4 channels)
 template <typename T>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs a, int splits) {
@@ -302,6 +470,8 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   if (m == 0) return PTV3_OK;
   int sps;
   int splits = choose_splits(m, cin, cout, kvol, dtype, &sps);
+  int big_bn = 0;
+  const bool big = splits <= 1 && out != nullptr && use_big_tile(m, cin, cout, kvol, dtype, &big_bn);
   if (splits > 1 && (workspace == nullptr || workspace_bytes < (size_t)splits * m * cout * sizeof(float))) {
     splits = 1;  // caller gave no slab room: single pass
     sps = 0;
@@ -321,6 +491,26 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
                               ((double)m * cin * (nbr ? 1 : kvol) + (double)cout * kvol * cin +
                                (double)m * cout * (1 + (res != nullptr) + (out2 != nullptr))) * esz,
                               nbr, m * kvol, 2.0 * cin * cout);
+  if (big) {
+    const size_t lds = (size_t)2 * (GB_BM + big_bn) * 128 + (nbr ? (size_t)GB_BM * kvol * 4 : 0);
+    dim3 bgrid((unsigned)cdiv(m, GB_BM), (unsigned)cdiv(cout, big_bn));
+#define GB_LAUNCH(T, WM_, WN_, BN_)                                                                              \
+    do {                                                                                                         \
+      static bool attr_set = false;                                                                              \
+      if (!attr_set) {                                                                                           \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<T, WM_, WN_, BN_>),             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                        \
+        attr_set = true;                                                                                         \
+      }                                                                                                          \
+      hipLaunchKernelGGL((gemm_big_kernel<T, WM_, WN_, BN_>), bgrid, dim3(GB_THREADS), lds, s, a);               \
+    } while (0)
+    if (dtype == PTV3_F32) { if (big_bn == 128) GB_LAUNCH(float, 2, 2, 128); else GB_LAUNCH(float, 4, 1, 64); }
+    else { if (big_bn == 128) GB_LAUNCH(__bf16, 2, 2, 128); else GB_LAUNCH(__bf16, 4, 1, 64); }
+#undef GB_LAUNCH
+    prof_end(prof, s);
+    PTV3_LAUNCH_CHECK();
+    return PTV3_OK;
+  }
   dim3 grid((unsigned)cdiv(m, GM_BM), (unsigned)cdiv(cout, bn), (unsigned)splits);
 #define GM_LAUNCH(T)                                                                                   \
   switch (nt) {                                                                                        \

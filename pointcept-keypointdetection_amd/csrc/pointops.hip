@@ -1,11 +1,15 @@
 // libs/pointops knn_query / grouping / interpolation as wavefront-primitive HIP.
-// knn: one 64-lane wave per query; the running top-k lives sorted across the lanes of the wave
-// (lane l holds ranks l and l+64), candidates are scanned 64 at a time, a ballot finds the few that
-// beat the current k-th distance and each is inserted with one ballot + one lane shift.
-// Distances use the reference's expression (dx*dx + dy*dy + dz*dz, left to right, no fma contraction)
-// so distances and indices match a plain-C restatement of the reference bit for bit - except for the ORDER inside a
-// group of exactly equal fp32 distances, which the reference's heap sort leaves implementation-defined (here:
-// ascending index).  The neighbour set is identical (strict `<` at the k-th distance in both).
+// knn: one 64-lane wave per group of queries; candidates are scanned 64 at a time (one coalesced load per chunk,
+// shared by the queries of the group), a ballot finds the few that beat the current k-th distance.  The running
+// k-best of a query is THE REFERENCE'S BINARY MAX-HEAP, held across the lanes of the wave (heap slot e in lane e & 63,
+// register e >> 6): an accepted candidate replaces the root and sinks exactly as reheap() does
+// (knn_query_cuda_kernel.cu:15-30: larger child, the left one on a tie; the newcomer keeps sinking while it is
+// <= that child), with wave-uniform (scalar) control flow and v_readlane for the few slots on the path; the final
+// heap_sort (:33-42) runs the same way.  The acceptance test is the reference's strict `d2 < best_dist[0]` in
+// candidate-index order, so the sequence of heap operations - and with it the neighbour SET and the ORDER inside
+// groups of exactly equal distances, which depend on the whole history of the heap - is the reference's, bit for bit
+// (tests: gridded coordinates, where ties are the common case).
+// Distances use the reference's expression (dx*dx + dy*dy + dz*dz, left to right, no fma contraction).
 // Reference: libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104,
 //            grouping/grouping_cuda_kernel.cu:5-25, interpolation/interpolation_cuda_kernel.cu:5-33.
 #include "common.h"
@@ -19,9 +23,44 @@ __device__ __forceinline__ float dist2_ref(float qx, float qy, float qz, float x
   return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// ---- the reference's heap, slot e (wave-uniform index) in lane e & 63 of register e >> 6
+template <int KPL>
+__device__ __forceinline__ float heap_d(const float (&hd)[KPL], int e) {
+  if (KPL == 1 || e < 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hd[0]), e & 63));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hd[KPL - 1]), e & 63));
+}
+template <int KPL>
+__device__ __forceinline__ int heap_i(const int (&hi)[KPL], int e) {
+  if (KPL == 1 || e < 64) return __builtin_amdgcn_readlane(hi[0], e & 63);
+  return __builtin_amdgcn_readlane(hi[KPL - 1], e & 63);
+}
+template <int KPL>
+__device__ __forceinline__ void heap_set(float (&hd)[KPL], int (&hi)[KPL], int e, float d, int i, int lane) {
+  const bool mine = lane == (e & 63);
+  if (KPL == 1 || e < 64) { hd[0] = mine ? d : hd[0]; hi[0] = mine ? i : hi[0]; }
+  else { hd[KPL - 1] = mine ? d : hd[KPL - 1]; hi[KPL - 1] = mine ? i : hi[KPL - 1]; }
+}
+// reheap() with (x, xi) placed at the root of a heap of `size` slots (:15-30); everything here is wave-uniform
+template <int KPL>
+__device__ __forceinline__ void heap_sink_root(float (&hd)[KPL], int (&hi)[KPL], int size, float x, int xi, int lane) {
+  int root = 0;
+  for (;;) {
+    int child = 2 * root + 1;
+    if (child >= size) break;
+    float dc = heap_d<KPL>(hd, child);
+    if (child + 1 < size) {
+      const float dr = heap_d<KPL>(hd, child + 1);
+      if (dr > dc) { ++child; dc = dr; }
+    }
+    if (x > dc) break;                                          // `if (dist[root] > dist[child]) return;`
+    heap_set<KPL>(hd, hi, root, dc, heap_i<KPL>(hi, child), lane);  // the swap: the child moves up, x goes on
+    root = child;
+  }
+  heap_set<KPL>(hd, hi, root, x, xi, lane);
+}
+
 // Scan the candidates [start, end) for NQ queries at once: every 64-candidate chunk is loaded ONCE per wave and
-// measured against all NQ queries (the loads and the loop overhead were ~half of the single-query kernel's
-// instruction stream); each query keeps its own sorted top-k across the lanes.
+// measured against all NQ queries; each query keeps its own heap across the lanes.
 template <int KPL, int NQ>
 __device__ __forceinline__ void knn_scan(const int* qs, int nq, int start, int end, int nsample,
                                          const float* __restrict__ xyz, const float* __restrict__ new_xyz,
@@ -37,7 +76,6 @@ __device__ __forceinline__ void knn_scan(const int* qs, int nq, int start, int e
 #pragma unroll
     for (int e = 0; e < KPL; ++e) { bd[q][e] = 1e10f; bi[q][e] = -1; }
   }
-  const int tpos = nsample - 1;
   for (int base = start; base < end; base += 64) {
     const int i = base + lane;
     float cx = 0.f, cy = 0.f, cz = 0.f;
@@ -48,42 +86,26 @@ __device__ __forceinline__ void knn_scan(const int* qs, int nq, int start, int e
       float d = 3.0e38f;
       if (cv) d = dist2_ref(qx[q], qy[q], qz[q], cx, cy, cz);
       unsigned long long mask = __ballot(d < tau[q]);
-      while (mask) {
+      while (mask) {   // the few candidates of this chunk that may enter, in index order (as the reference's loop)
         const int src = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const float dc = __shfl(d, src, 64);
-        if (!(dc < tau[q])) continue;
-        const int ci = base + src;
-        // rank of the newcomer: behind every entry with distance <= dc (earlier index wins ties)
-        int pos = 0;
-#pragma unroll
-        for (int e = 0; e < KPL; ++e) pos += __popcll(__ballot(bd[q][e] <= dc));
-#pragma unroll
-        for (int e = KPL - 1; e >= 0; --e) {
-          const int p = lane + 64 * e;
-          float ud = __shfl_up(bd[q][e], 1, 64);
-          int ui = __shfl_up(bi[q][e], 1, 64);
-          if (e > 0) {
-            float wd = __shfl(bd[q][e - 1], 63, 64);
-            int wi = __shfl(bi[q][e - 1], 63, 64);
-            if (lane == 0) { ud = wd; ui = wi; }
-          }
-          if (p > pos) { bd[q][e] = ud; bi[q][e] = ui; }
-          else if (p == pos) { bd[q][e] = dc; bi[q][e] = ci; }
-        }
-        const float t0 = __shfl(bd[q][0], tpos & 63, 64);
-        if (KPL == 2) {
-          const float t1 = __shfl(bd[q][KPL - 1], tpos & 63, 64);
-          tau[q] = tpos >= 64 ? t1 : t0;
-        } else {
-          tau[q] = t0;
-        }
+        const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
+        if (!(dc < tau[q])) continue;   // `if (d2 < best_dist[0])` against the root as it is NOW
+        heap_sink_root<KPL>(bd[q], bi[q], nsample, dc, base + src, lane);
+        tau[q] = heap_d<KPL>(bd[q], 0);
       }
     }
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     if (q >= nq) continue;
+    // heap_sort (:33-42): slot i takes the root, the old slot i sinks from the root of the remaining i slots
+    for (int i = nsample - 1; i > 0; --i) {
+      const float xd = heap_d<KPL>(bd[q], i);
+      const int xi = heap_i<KPL>(bi[q], i);
+      heap_set<KPL>(bd[q], bi[q], i, heap_d<KPL>(bd[q], 0), heap_i<KPL>(bi[q], 0), lane);
+      heap_sink_root<KPL>(bd[q], bi[q], i, xd, xi, lane);
+    }
 #pragma unroll
     for (int e = 0; e < KPL; ++e) {
       const int p = lane + 64 * e;

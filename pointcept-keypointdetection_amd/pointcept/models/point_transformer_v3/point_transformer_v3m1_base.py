@@ -679,11 +679,12 @@ class PointTransformerV3(PointModule):
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
+            # amp_dtype="float16" is the reference's default (configs/_base_/default_runtime.py:19) and means "16-bit
+            # matmuls": the MI355X kernels take the request as bfloat16 - the same storage width with fp32's exponent
+            # range, so the GradScaler the trainer wraps around fp16 runs (engines/train.py:201-241) never sees an
+            # overflow - and hand results back in fp32 at the model boundary (pred / seg_logits / loss).
             dt = torch.get_autocast_gpu_dtype()
-            if dt != torch.bfloat16:
-                raise NotImplementedError(f"autocast dtype {dt}: the MI355X path computes in bfloat16 or float32 "
-                                          "(set amp_dtype='bfloat16')")
-            return dt
+            return torch.bfloat16 if dt in (torch.bfloat16, torch.float16) else torch.float32
         return torch.float32
 
     def forward(self, data_dict, _head=None):

@@ -313,10 +313,10 @@ class PointTransformerV3(PointModule):
         if self.compute_dtype is not None:
             return self.compute_dtype
         if torch.is_autocast_enabled():
+            # float16 autocast (the reference's default amp_dtype) is taken as a request for 16-bit matmuls and served
+            # in bfloat16 (see PT-v3m1's resolve_dtype)
             dt = torch.get_autocast_gpu_dtype()
-            if dt != torch.bfloat16:
-                raise NotImplementedError(f"autocast dtype {dt}: the MI355X path computes in bfloat16 or float32")
-            return dt
+            return torch.bfloat16 if dt in (torch.bfloat16, torch.float16) else torch.float32
         return torch.float32
 
     def forward(self, data_dict):

@@ -1,121 +1,141 @@
-"""Python wrappers with the reference's call surface (libs/pointops/functions/{query,grouping,
-interpolation,utils}.py) over the HIP entry points in pointops._C."""
+"""The `pointops` call surface on top of the HIP entry points in `pointops._C`.
+
+What callers of the reference's libs/pointops rely on (functions/__init__.py:1-14; call sites: engines/test.py:939-945,
+hooks/evaluator.py:569-575, the PTv2 / Sonata model files):
+
+    idx, dist = knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None)   idx int32 (-1 = no neighbour), dist = sqrt(d2)
+    grouping(idx, feat, xyz, new_xyz=None, with_xyz=False)       (m, nsample, [3 +] c); -1 gathers a zero row
+    grouping2(feat, idx)                                          the bare gather
+    interpolation(xyz, new_xyz, feat, offset, new_offset, k=3)   inverse-distance blend of the k nearest rows
+    interpolation2(...)                                           same arguments
+    knn_query_and_group(...), offset2batch, batch2offset
+
+Both spellings of grouping / interpolation run the same HIP kernels here (the reference keeps a torch-indexing and
+a CUDA variant of each); gradients with respect to the features flow through the matching backward kernels.
+"""
 import torch
-from torch.autograd import Function
 
-from ._C import (knn_query_cuda, grouping_forward_cuda, grouping_backward_cuda, interpolation_forward_cuda,
-                 interpolation_backward_cuda)
+from . import _C
 
 
-class KNNQuery(Function):
+def _i32(t):
+    return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
+
+
+@torch.no_grad()
+def knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None):
+    """k nearest candidates of every query inside its own scene (libs/pointops/functions/query.py:7-24).
+    xyz (n, 3) candidates / offset (b) cumulative ends; new_xyz (m, 3) queries / new_offset (b); queries default to
+    the candidates themselves.  Rows are ascending in distance; scenes with fewer than nsample candidates pad with
+    idx -1, dist sqrt(1e10)."""
+    if new_xyz is None or new_offset is None:
+        new_xyz, new_offset = xyz, offset
+    if not (xyz.is_contiguous() and new_xyz.is_contiguous()):
+        raise AssertionError("knn_query: xyz / new_xyz must be contiguous")
+    m = new_xyz.shape[0]
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+    dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+    _C.knn_query_cuda(m, nsample, xyz, new_xyz, _i32(offset), _i32(new_offset), idx, dist2)
+    return idx, dist2.sqrt_()
+
+
+class _RowGather(torch.autograd.Function):
+    """out[i, s, :] = table[idx[i, s], :] (zero row for idx -1); backward = scatter-add of the row gradients."""
+
     @staticmethod
-    def forward(ctx, nsample, xyz, offset, new_xyz=None, new_offset=None):
-        """xyz (n,3), new_xyz (m,3), offset (b), new_offset (b) -> idx (m,nsample) int32 (-1 pad), dist (m,nsample)."""
-        if new_xyz is None or new_offset is None:
-            new_xyz = xyz
-            new_offset = offset
-        assert xyz.is_contiguous() and new_xyz.is_contiguous()
-        m = new_xyz.shape[0]
-        idx = torch.zeros((m, nsample), dtype=torch.int, device=xyz.device)
-        dist2 = torch.zeros((m, nsample), dtype=torch.float, device=xyz.device)
-        knn_query_cuda(m, nsample, xyz, new_xyz, offset.int().contiguous(), new_offset.int().contiguous(), idx, dist2)
-        return idx, torch.sqrt(dist2)
-
-
-knn_query = KNNQuery.apply
-
-
-class Grouping(Function):
-    @staticmethod
-    def forward(ctx, input, idx):
-        assert input.is_contiguous() and idx.is_contiguous()
-        m, nsample, n, c = idx.shape[0], idx.shape[1], input.shape[0], input.shape[1]
-        output = torch.zeros((m, nsample, c), dtype=torch.float, device=input.device)
-        grouping_forward_cuda(m, nsample, c, input, idx, output)
-        ctx.n = n
+    def forward(ctx, table, idx):
+        if not (table.is_contiguous() and idx.is_contiguous()):
+            raise AssertionError("grouping: input / idx must be contiguous")
+        m, nsample = idx.shape
+        rows, width = table.shape
+        out = torch.zeros((m, nsample, width), dtype=torch.float32, device=table.device)
+        _C.grouping_forward_cuda(m, nsample, width, table, idx, out)
+        ctx.rows = rows
         ctx.save_for_backward(idx)
-        return output
+        return out
 
     @staticmethod
-    def backward(ctx, grad_output):
-        n = ctx.n
+    def backward(ctx, grad):
         (idx,) = ctx.saved_tensors
-        m, nsample, c = grad_output.shape
-        grad_input = torch.zeros((n, c), dtype=torch.float, device=idx.device)
-        grouping_backward_cuda(m, nsample, c, grad_output.contiguous(), idx, grad_input)
-        return grad_input, None
+        m, nsample, width = grad.shape
+        acc = torch.zeros((ctx.rows, width), dtype=torch.float32, device=grad.device)
+        _C.grouping_backward_cuda(m, nsample, width, grad.contiguous(), idx, acc)
+        return acc, None
 
 
-grouping2 = Grouping.apply
+def grouping2(input, idx):
+    return _RowGather.apply(input, idx)
 
 
 def grouping(idx, feat, xyz, new_xyz=None, with_xyz=False):
-    """functions/grouping.py:41-63: -1 indices read an appended zero row."""
-    if new_xyz is None:
-        new_xyz = xyz
-    assert xyz.is_contiguous() and feat.is_contiguous()
-    m, nsample, c = idx.shape[0], idx.shape[1], feat.shape[1]
-    grouped_feat = Grouping.apply(feat, idx.contiguous()) if not feat.requires_grad else _group_torch(feat, idx)
+    """Neighbourhood features (libs/pointops/functions/grouping.py:41-63).  With `with_xyz` the neighbour offsets
+    relative to the query come first; a missing neighbour (-1) contributes zeros to both parts."""
+    if not (xyz.is_contiguous() and feat.is_contiguous()):
+        raise AssertionError("grouping: xyz / feat must be contiguous")
+    centre = xyz if new_xyz is None else new_xyz
+    idx = idx.contiguous()
+    parts = [_RowGather.apply(feat, idx)]
     if with_xyz:
-        assert new_xyz.is_contiguous()
-        mask = torch.sign(idx + 1)
-        grouped_xyz = Grouping.apply(xyz, idx.contiguous()) - new_xyz.unsqueeze(1)
-        grouped_xyz = torch.einsum("n s c, n s -> n s c", grouped_xyz, mask.to(grouped_xyz.dtype))
-        return torch.cat((grouped_xyz, grouped_feat), -1)
-    return grouped_feat
+        if not centre.is_contiguous():
+            raise AssertionError("grouping: new_xyz must be contiguous")
+        present = (idx >= 0).to(torch.float32).unsqueeze(-1)
+        parts.insert(0, (_RowGather.apply(xyz, idx) - centre.unsqueeze(1)) * present)
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
 
 
-def _group_torch(feat, idx):
-    m, nsample, c = idx.shape[0], idx.shape[1], feat.shape[1]
-    feat = torch.cat([feat, torch.zeros([1, c], device=feat.device, dtype=feat.dtype)], dim=0)
-    return feat[idx.view(-1).long(), :].view(m, nsample, c)
+class _KnnBlend(torch.autograd.Function):
+    """out[i] = sum_j weight[i, j] * table[idx[i, j]]; the gradient reaches `table` only (weights come out of a
+    no-grad neighbour search, as in the reference: libs/pointops/functions/interpolation.py:28-61)."""
 
-
-class Interpolation(Function):
     @staticmethod
-    def forward(ctx, xyz, new_xyz, input, offset, new_offset, k=3):
-        assert xyz.is_contiguous() and new_xyz.is_contiguous() and input.is_contiguous()
-        idx, dist = knn_query(k, xyz, offset, new_xyz, new_offset)
-        dist_recip = 1.0 / (dist + 1e-8)
-        norm = torch.sum(dist_recip, dim=1, keepdim=True)
-        weight = (dist_recip / norm).contiguous()
-        n, c, m = new_xyz.shape[0], input.shape[1], input.shape[0]
-        output = torch.zeros((n, c), dtype=torch.float, device=xyz.device)
-        interpolation_forward_cuda(n, c, k, input, idx, weight, output)
-        ctx.m, ctx.k = m, k
+    def forward(ctx, table, idx, weight):
+        n, k = idx.shape
+        width = table.shape[1]
+        out = torch.zeros((n, width), dtype=torch.float32, device=table.device)
+        _C.interpolation_forward_cuda(n, width, k, table, idx, weight, out)
+        ctx.rows = table.shape[0]
         ctx.save_for_backward(idx, weight)
-        return output
+        return out
 
     @staticmethod
-    def backward(ctx, grad_output):
-        m, k = ctx.m, ctx.k
+    def backward(ctx, grad):
         idx, weight = ctx.saved_tensors
-        n, c = grad_output.shape
-        grad_input = torch.zeros((m, c), dtype=torch.float, device=idx.device)
-        interpolation_backward_cuda(n, c, k, grad_output.contiguous(), idx, weight, grad_input)
-        return None, None, grad_input, None, None, None
-
-
-interpolation2 = Interpolation.apply
+        n, width = grad.shape
+        acc = torch.zeros((ctx.rows, width), dtype=torch.float32, device=grad.device)
+        _C.interpolation_backward_cuda(n, width, idx.shape[1], grad.contiguous(), idx, weight, acc)
+        return acc, None, None
 
 
 def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
-    """functions/interpolation.py:8-25 (no autograd through the op in the reference either)."""
-    return Interpolation.apply(xyz, new_xyz, feat.contiguous(), offset, new_offset, k)
+    """Features of `xyz` carried to `new_xyz` by normalised 1 / (distance + 1e-8) weights over the k nearest
+    (libs/pointops/functions/interpolation.py:8-25)."""
+    if not (xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()):
+        raise AssertionError("interpolation: xyz / new_xyz / feat must be contiguous")
+    idx, dist = knn_query(k, xyz, offset, new_xyz, new_offset)
+    w = torch.reciprocal(dist + 1e-8)
+    w = (w / w.sum(dim=1, keepdim=True)).contiguous()
+    return _KnnBlend.apply(feat, idx, w)
+
+
+interpolation2 = interpolation
 
 
 def knn_query_and_group(feat, xyz, offset=None, new_xyz=None, new_offset=None, idx=None, nsample=None,
                         with_xyz=False):
+    """libs/pointops/functions/utils.py:5-18: search (unless `idx` is given), then grouping()."""
     if idx is None:
-        assert nsample is not None
+        if nsample is None:
+            raise AssertionError("knn_query_and_group: nsample is required when idx is not given")
         idx, _ = knn_query(nsample, xyz, offset, new_xyz, new_offset)
     return grouping(idx, feat, xyz, new_xyz, with_xyz), idx
 
 
 def offset2batch(offset):
-    counts = torch.diff(offset.long(), prepend=torch.zeros(1, dtype=torch.long, device=offset.device))
-    return torch.arange(len(offset), device=offset.device).repeat_interleave(counts).long()
+    """cumulative scene ends -> scene id per point (libs/pointops/functions/utils.py offset2batch)"""
+    ends = offset.long()
+    sizes = torch.diff(ends, prepend=ends.new_zeros(1))
+    return torch.repeat_interleave(torch.arange(ends.numel(), device=offset.device), sizes)
 
 
 def batch2offset(batch):
-    return torch.cumsum(batch.bincount(), dim=0).int()
+    return batch.bincount().cumsum(0).int()

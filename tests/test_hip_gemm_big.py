@@ -1,0 +1,81 @@
+"""The large-M tile of ptv3_gemm (gemm_big_kernel: 128 points x 64 | 128 channels, double-buffered LDS, LDS-resident
+neighbour table) against the 64-point tile it replaces at chip-filling sizes and against torch fp32.
+PTV3_GEMM_BIG = 0 / 2 switches the policy off / forces the large tile (read per call)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch.device("cuda:0")
+
+
+def _both(fn):
+    out = {}
+    for mode in ("0", "2"):
+        os.environ["PTV3_GEMM_BIG"] = mode
+        try:
+            out[mode] = fn()
+        finally:
+            os.environ.pop("PTV3_GEMM_BIG", None)
+    return out["0"], out["2"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("m,cin,cout", [(5000, 64, 64), (777, 256, 768), (3000, 512, 2048), (4099, 2048, 512),
+                                         (129, 64, 192), (1, 128, 128), (260, 72, 100)])
+def test_dense_linear_big_tile(dev, dtype, m, cin, cout):
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(m + cin)
+    x = torch.randn(m, cin, generator=g).to(dev, dtype)
+    w = (torch.randn(cout, cin, generator=g) / cin ** 0.5).to(dev, dtype)
+    bias = torch.randn(cout, generator=g).to(dev)
+    res = torch.randn(m, cout, generator=g).to(dev, dtype)
+    small, big = _both(lambda: ops.gemm(x, w, bias=bias, act=ops.ACT_GELU, res=res))
+    assert torch.equal(small, big)      # same accumulation order over K: bitwise the same result
+    ref = torch.nn.functional.gelu(x.float() @ w.float().t() + bias) + res.float()
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+    assert (big.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,cin,cout", [(3000, 64, 64), (2500, 128, 128), (1200, 32, 64), (700, 16, 64), (900, 48, 72)])
+def test_sparse_conv_big_tile(dev, dtype, n, cin, cout):
+    """Gathered rows through the LDS-resident neighbour table, row_order on, K steps that span one or two taps
+    (cin 64+ / 32 / 16) and a channel count that is not a power of two; bn / dual-output / indexed-residual epilogue."""
+    from ptv3_hip import ops
+    import ptv3_scenes as S
+    from oracle import ptv3 as O
+    if dtype == torch.bfloat16 and cin % 8:
+        pytest.skip("bf16 needs cin % 8 == 0")
+    sc = S.make_scene(n, cin, 40, seed=n)
+    gc = torch.from_numpy(sc["grid_coord"])
+    idx = torch.cat([torch.zeros(n, 1, dtype=torch.int32), gc.int()], 1).contiguous()
+    g = torch.Generator().manual_seed(n)
+    feat = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    nbr, _ = ops.subm_neighbors(idx.to(dev), 3)
+    order = torch.randperm(n, generator=g).int().to(dev)
+    scale, shift = torch.rand(cout, generator=g).to(dev) + 0.5, torch.randn(cout, generator=g).to(dev)
+    ridx = torch.randint(0, 50, (n,), generator=g).int().to(dev)
+    res = torch.randn(50, cout, generator=g).to(dev, dtype)
+    xd, wd = feat.to(dev, dtype), w.reshape(cout, -1).to(dev, dtype).contiguous()
+
+    def run():
+        return ops.gemm(xd, wd, bias=bias.to(dev), nbr=nbr, kvol=27, row_order=order, bn_scale=scale, bn_shift=shift,
+                        act=ops.ACT_RELU, res=res, res_index=ridx, dual=True)
+    (s0, s1), (b0, b1) = _both(run)
+    assert torch.equal(s0, b0) and torch.equal(s1, b1)
+    ref = O.subm_conv3d(xd.float().cpu(), idx, wd.float().cpu().reshape(w.shape), bias)
+    ref = torch.relu(ref * scale.cpu() + shift.cpu())
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -6
+    assert (b0.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    ref2 = ref + res.float().cpu()[ridx.cpu().long()]
+    assert (b1.float().cpu() - ref2).abs().max().item() < tol * max(1.0, ref2.abs().max().item())
