@@ -87,8 +87,8 @@ def pmc_traffic(args, kernel_family):
     w = data.get("workload", {})
     if (w.get("points"), w.get("scenes"), w.get("dtype"), w.get("kind")) != (args.points, args.scenes, args.dtype, args.kind):
         return None, None
-    key = {"linear": "gemm_kernel<bf16,64ch>", "subm_conv": "gemm_kernel<bf16,64ch>",
-           "window_attn": "window_attn_full_kernel"}.get(kernel_family)
+    key = kernel_family.split(" ")[0]   # "gemm_kernel<64ch> dense" -> the rocprof kernel name prefix
+    key = {"gemm_kernel<64ch>": "gemm_kernel<bf16,64ch>", "gemm_kernel<32ch>": "gemm_kernel<bf16,32ch>"}.get(key, key)
     k = data["kernels"].get(key)
     if not k:
         return None, None
@@ -454,17 +454,29 @@ def run(args):
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        kern = ops.profile_collect_kernels()   # per KERNEL (one launch per bracket); before the family collect
         fam = ops.profile_collect()
         ops.profile_enable(False)
-        dom = max(fam, key=lambda k: fam[k]["ms"])
-        d = fam[dom]
+        # the dominant KERNEL (not family): its algorithmic bytes / flops per launch over its average launch duration -
+        # the quantity a rocprofv3 --kernel-trace --stats summary of this command gives for the same kernel name
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        d = kern[dom]
         tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
         gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        # which roof binds this family: algorithmic intensity against the machine balance of the dtype
+        # which roof binds it: algorithmic intensity against the machine balance of the dtype
         intensity = d["flops"] / max(d["bytes"], 1.0)
         hbm_bound = intensity * PEAK_HBM * 1e9 < PEAK[args.dtype] * 1e12
-        roofline = {"kernel": dom, "measured": f"HIP events on the launch stream, {args.steps} extra steps after the timed region, one forward "
-                                "in flight",
+
+        def per_kernel(v):
+            n = max(1, v["launches"])
+            return {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+                    "avg_launch_us": round(v["ms"] * 1e3 / n, 2),
+                    "algorithmic_mb_per_launch": round(v["bytes"] / n / 1e6, 4),
+                    "algorithmic_gflop_per_launch": round(v["flops"] / n / 1e9, 4),
+                    "gbps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
+        roofline = {"kernel": dom, "measured": f"HIP events on the launch stream around every launch of the kernel, {args.steps} extra "
+                                "steps after the timed region, one forward in flight",
                     "bound": "hbm" if hbm_bound else "mfma",
                     "achieved": round(gbs if hbm_bound else tf, 3),
                     "peak": PEAK_HBM if hbm_bound else PEAK[args.dtype],
@@ -478,7 +490,8 @@ def run(args):
                     "algorithmic_mb_per_step": round(d["bytes"] / args.steps / 1e6, 3),
                     "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()},
                     "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()},
-                    "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()}}
+                    "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()},
+                    "kernels": {k: per_kernel(v) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
         if rank == 0:
             roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(args, roofline["kernel"])
             if (args.points, args.scenes, args.dtype, args.kind, args.model) == (100000, 1, "bf16", "surface", "offset"):

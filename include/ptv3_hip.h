@@ -361,6 +361,17 @@ int ptv3_window_attn_varlen_bwd(const void* qkv, const void* out, const void* do
                                 const int32_t* win_inverse, const int32_t* cu_seqlens, int num_windows, void* dqkv,
                                 int64_t n, int64_t n_pad, int c, int heads, int max_seqlen, float scale, int dtype,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* backward of ptv3_window_attn_rpe_fwd: dqkv as above with the relative-position bias inside the recomputed softmax,
+ * plus the gradient of the bias table, dtable (3*(2*pos_bnd+1), heads) fp32 = sum over all (window, query, key) pairs
+ * of dS routed to the three (axis, clamped coordinate difference) entries the pair read (RPE.forward,
+ * point_transformer_v3m1_base.py:29-48, differentiated).  Per-workgroup partial columns are summed in a fixed order.
+ * PTV3_ERR_UNSUPPORTED when 3*(2*pos_bnd+1) > 1024. */
+size_t ptv3_window_attn_rpe_bwd_workspace_bytes(int64_t n, int64_t n_pad, int c, int heads, int patch, int pos_bnd,
+                                                int dtype);
+int ptv3_window_attn_rpe_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                             const int32_t* win_inverse, const int32_t* grid_coord, const float* rpe_table,
+                             int pos_bnd, void* dqkv, float* dtable, int64_t n, int64_t n_pad, int c, int heads,
+                             int patch, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* fused multi-tensor AdamW (torch.optim.AdamW semantics; pointcept/utils/optimizer.py builds it with one
  * extra "block" parameter group): a device table of ptv3_adamw_entry_bytes()-sized entries, filled on the
  * host by ptv3_adamw_fill_entry; entry i owns blocks [first_block_i, first_block_i + ceil(numel_i / chunk)).
@@ -424,6 +435,13 @@ int ptv3_keypoint_aggregate(const float* coord, const float* pred, const int64_t
  * neighbour), algorithmic bytes and launch count since enable / the last collect. */
 int ptv3_profile_enable(int on);
 int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches);
+/* the same records by KERNEL (one launch per bracket): arrays of ptv3_profile_kernel_count() entries, entry i is the
+ * kernel ptv3_profile_kernel_name(i) (gemm_kernel 64 / 32 channel tiles and gemm_big_kernel each split into their
+ * dense and gathered = sparse-conv launches, the fused block halves, mlp2, the two window-attention kernels).  Does not
+ * reset the records: call it BEFORE ptv3_profile_collect. */
+int ptv3_profile_kernel_count(void);
+const char* ptv3_profile_kernel_name(int kernel);
+int ptv3_profile_collect_kernels(double* ms, double* flops, double* bytes, int64_t* launches);
 
 /* ---- pointops (libs/pointops) ------------------------------------------------------------------
  * Same argument meaning as the reference's extern "C" launchers

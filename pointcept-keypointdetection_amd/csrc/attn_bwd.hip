@@ -22,7 +22,23 @@ struct AttnBwdArgs {
   int c, heads, patch, nwin;
   float scale, scale_log2e;
   const int32_t* cu;  // ragged windows (ptv3_window_attn_varlen_bwd): slots [cu[w], cu[w+1]) of window w, else NULL
+  // relative-position bias (RPE, point_transformer_v3m1_base.py:29-48): score += sum_axis table[axis][clamp(dgrid)][head].
+  // grid (n, 3) int32 voxel coordinates in point order, table (3 * rpe_num, heads) fp32; dtab_slab receives one partial
+  // table-column gradient [3 * rpe_num] per workgroup of pass A (summed per head in block order afterwards)
+  const int32_t* grid; const float* table; int pos_bnd; float* dtab_slab;
 };
+
+constexpr int AB_MAX_TAB = 1024;  // 3 * (2 * pos_bnd + 1) entries of one head's table column held in LDS
+
+// bias of the pair (query coordinates qg, key coordinates kg) from one head's table column (already in the caller's
+// unit: natural for the gradient bins, x log2(e) for the softmax recompute)
+__device__ __forceinline__ float rpe_pair_bias(const float* __restrict__ tab, const int* qg, const int* kg, int bnd,
+                                               int rpe_num) {
+  float b = 0.f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) b += tab[d * rpe_num + min(max(qg[d] - kg[d], -bnd), bnd) + bnd];
+  return b;
+}
 
 template <int ND> struct AbCfg {
   static constexpr int D = 16 * ND;
@@ -33,13 +49,17 @@ template <int ND> struct AbCfg {
 // -------------------------------------------------------------------------------------------------
 // pass A: lane = query.  Streams K, V (and K^T) of the window through LDS.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int ND>
+template <typename T, int ND, bool RPE>
 __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = AbCfg<ND>::D, CT = AbCfg<ND>::CT, TS = AbCfg<ND>::TS;
   __shared__ __attribute__((aligned(16))) T sK[CT * D];
   __shared__ __attribute__((aligned(16))) T sV[CT * D];
   __shared__ __attribute__((aligned(16))) T sKt[D * TS];
+  __shared__ int sG[RPE ? CT * 3 : 1];              // voxel coordinates of the streamed keys
+  __shared__ float sTab[RPE ? AB_MAX_TAB : 1];      // this head's table column x log2(e)
+  __shared__ float sHist[RPE ? 4 * AB_MAX_TAB : 1]; // per-wave gradient bins of the column
+  const int rpe_num = 2 * a.pos_bnd + 1;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
@@ -73,10 +93,25 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
   }
   dpart += __shfl_xor(dpart, 16, 64);
   const float delta = dpart + __shfl_xor(dpart, 32, 64);
+  int qg[3] = {0, 0, 0};
+  if constexpr (RPE) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) qg[d] = a.grid[src * 3 + d];
+    for (int j = threadIdx.x; j < 3 * rpe_num; j += 256) sTab[j] = a.table[(int64_t)j * a.heads + h] * 1.44269504088896340736f;
+    for (int j = threadIdx.x; j < 4 * 3 * rpe_num; j += 256) sHist[j] = 0.f;
+  }
 
   const int nchunks = (P + CT - 1) / CT;
   auto load_chunk = [&](int kc0, bool with_v) {
     __syncthreads();
+    if constexpr (RPE) {
+      for (int u = threadIdx.x; u < CT; u += 256) {
+        const bool kv_ = kc0 + u < P;
+        const int64_t ks = kv_ ? a.win_order[slot0 + kc0 + u] : 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sG[3 * u + d] = kv_ ? a.grid[ks * 3 + d] : 0;
+      }
+    }
     for (int u = threadIdx.x; u < CT * (D / 4); u += 256) {
       const int key = u / (D / 4), dv = u % (D / 4);
       V4 kv = zero4<T>(), vv = zero4<T>();
@@ -115,6 +150,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         t[r] = kc0 + 16 * kt + 4 * g + r < P ? s[r] * a.scale_log2e : -INFINITY;
+        if constexpr (RPE) t[r] += rpe_pair_bias(sTab, qg, sG + 3 * (16 * kt + 4 * g + r), a.pos_bnd, rpe_num);
         mx = fmaxf(mx, t[r]);
       }
       if (mx == -INFINITY) continue;
@@ -151,8 +187,21 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
       float ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = kc0 + 16 * kt + 4 * g + r < P ? __builtin_amdgcn_exp2f(s[r] * a.scale_log2e - lse2) : 0.f;
+        const bool kin = kc0 + 16 * kt + 4 * g + r < P;
+        float sc = s[r] * a.scale_log2e;
+        const int* kg = sG + (RPE ? 3 * (16 * kt + 4 * g + r) : 0);
+        if constexpr (RPE) sc += rpe_pair_bias(sTab, qg, kg, a.pos_bnd, rpe_num);
+        const float p = kin ? __builtin_amdgcn_exp2f(sc - lse2) : 0.f;
         ds[r] = p * (dp[r] - delta);
+        if constexpr (RPE) {
+          // d loss / d bias(q, k) = dS: one bin per axis of this wave's copy of the column gradient
+          if (kin && qv) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d)
+              atomicAdd(&sHist[wave * 3 * rpe_num + d * rpe_num + min(max(qg[d] - kg[d], -a.pos_bnd), a.pos_bnd) + a.pos_bnd],
+                        ds[r]);
+          }
+        }
       }
       const V4 dsv = pack4<T>(ds[0], ds[1], ds[2], ds[3]);
 #pragma unroll
@@ -172,15 +221,24 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
       a.delta[p * a.heads + h] = delta;
     }
   }
+  if constexpr (RPE) {
+    __syncthreads();
+    for (int j = threadIdx.x; j < 3 * rpe_num; j += 256)   // the four wave copies in wave order
+      a.dtab_slab[(int64_t)blockIdx.x * 3 * rpe_num + j] =
+          ((sHist[j] + sHist[3 * rpe_num + j]) + sHist[2 * 3 * rpe_num + j]) + sHist[3 * 3 * rpe_num + j];
+  }
 }
 
 // -------------------------------------------------------------------------------------------------
 // pass B: lane = key.  Streams Q, dO (and their transposes), lse, delta of the window through LDS.
 // -------------------------------------------------------------------------------------------------
-template <typename T, int ND>
+template <typename T, int ND, bool RPE>
 __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = AbCfg<ND>::D, CT = AbCfg<ND>::CT, TS = AbCfg<ND>::TS;
+  __shared__ int sG[RPE ? CT * 3 : 1];          // voxel coordinates of the streamed queries
+  __shared__ float sTab[RPE ? AB_MAX_TAB : 1];  // this head's table column x log2(e)
+  const int rpe_num = 2 * a.pos_bnd + 1;
   __shared__ __attribute__((aligned(16))) T sQ[CT * D];
   __shared__ __attribute__((aligned(16))) T sO[CT * D];
   __shared__ __attribute__((aligned(16))) T sQt[D * TS];
@@ -210,6 +268,12 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
   f32x4 acck[ND], accv[ND];
 #pragma unroll
   for (int nd = 0; nd < ND; ++nd) acck[nd] = accv[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int kg[3] = {0, 0, 0};
+  if constexpr (RPE) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) kg[d] = a.grid[src * 3 + d];
+    for (int j = threadIdx.x; j < 3 * rpe_num; j += 256) sTab[j] = a.table[(int64_t)j * a.heads + h] * 1.44269504088896340736f;
+  }
 
   const int nchunks = (P + CT - 1) / CT;
   for (int ch = 0; ch < nchunks; ++ch) {
@@ -239,6 +303,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
       const bool v = qc0 + q < P;
       sL[q] = v ? a.lse[(slot0 + qc0 + q) * a.heads + h] : INFINITY;  // exp2(-inf) = 0 for the tail rows
       sDl[q] = v ? a.delta[(slot0 + qc0 + q) * a.heads + h] : 0.f;
+      if constexpr (RPE) {
+        const int64_t qs = v ? a.win_order[slot0 + qc0 + q] : 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) sG[3 * q + d] = v ? a.grid[qs * 3 + d] : 0;
+      }
     }
     __syncthreads();
     const int ntile = (min(CT, P - qc0) + 15) / 16;
@@ -253,7 +322,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int q = 16 * qt + 4 * g + r;
-        p[r] = __builtin_amdgcn_exp2f(s[r] * a.scale_log2e - sL[q]);
+        float sc = s[r] * a.scale_log2e;
+        if constexpr (RPE) sc += rpe_pair_bias(sTab, sG + 3 * q, kg, a.pos_bnd, rpe_num);
+        p[r] = __builtin_amdgcn_exp2f(sc - sL[q]);
         ds[r] = p[r] * (dp[r] - sDl[q]);
       }
       const V4 pv = pack4<T>(p[0], p[1], p[2], p[3]);
@@ -313,8 +384,26 @@ __global__ void __launch_bounds__(256) unpad_add_kernel(const T* __restrict__ dp
 template <typename T, int ND>
 static void launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
   const unsigned blocks = (unsigned)a.nwin * a.heads * ((a.patch + 63) / 64);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND>), dim3(blocks), dim3(256), 0, s, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND>), dim3(blocks), dim3(256), 0, s, a);
+  if (a.table) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND, true>), dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND, true>), dim3(blocks), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND, false>), dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND, false>), dim3(blocks), dim3(256), 0, s, a);
+  }
+}
+
+// dtable[j][h] = sum over the pass-A workgroups of head h (block id = (window * heads + h) * qblocks + qb) of their
+// partial columns, in block order: deterministic
+__global__ void __launch_bounds__(256) rpe_dtable_reduce_kernel(const float* __restrict__ slab, int nwin, int heads,
+                                                                 int qblocks, int ncol, float* __restrict__ dtable) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ncol * heads) return;
+  const int j = t / heads, h = t % heads;
+  float acc = 0.f;
+  for (int w = 0; w < nwin; ++w)
+    for (int qb = 0; qb < qblocks; ++qb) acc += slab[((int64_t)(w * heads + h) * qblocks + qb) * ncol + j];
+  dtable[t] = acc;
 }
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -329,10 +418,12 @@ extern "C" size_t ptv3_window_attn_bwd_workspace_bytes(int64_t n, int64_t n_pad,
          align256((size_t)n * sizeof(int32_t));
 }
 
+struct RpeBwd { const int32_t* grid; const float* table; int pos_bnd; float* dtable; };
+
 static int window_attn_bwd_impl(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
                                 const int32_t* win_inverse, const int32_t* cu, int nwin, void* dqkv, int64_t n,
                                 int64_t n_pad, int c, int heads, int patch, float scale, int dtype, void* workspace,
-                                hipStream_t s) {
+                                hipStream_t s, RpeBwd rpe = RpeBwd{nullptr, nullptr, 0, nullptr}) {
   const int d = c / heads;
   if (d != 16 && d != 32 && d != 64) {
     set_error("window_attn_bwd: head_dim %d unsupported (16, 32, 64)", d);
@@ -346,8 +437,9 @@ static int window_attn_bwd_impl(const void* qkv, const void* out, const void* do
   a.dqkv_pad = ws; ws += align256((size_t)n_pad * 3 * c * esz);
   a.lse = (float*)ws; ws += align256((size_t)n_pad * heads * sizeof(float));
   a.delta = (float*)ws; ws += align256((size_t)n_pad * heads * sizeof(float));
-  int32_t* dup = (int32_t*)ws;
+  int32_t* dup = (int32_t*)ws; ws += align256((size_t)n * sizeof(int32_t));
   a.c = c; a.heads = heads; a.patch = patch; a.nwin = nwin; a.cu = cu;
+  a.grid = rpe.grid; a.table = rpe.table; a.pos_bnd = rpe.pos_bnd; a.dtab_slab = (float*)ws;
   a.scale = scale; a.scale_log2e = scale * 1.44269504088896340736f;
   if (hipMemsetAsync(dup, 0xFF, (size_t)n * sizeof(int32_t), s) != hipSuccess) return PTV3_ERR_LAUNCH;
   hipLaunchKernelGGL(dup_slot_kernel, dim3((unsigned)cdiv(n_pad, 256)), dim3(256), 0, s, win_order, win_inverse, n_pad, dup);
@@ -366,8 +458,46 @@ static int window_attn_bwd_impl(const void* qkv, const void* out, const void* do
   else
     hipLaunchKernelGGL(unpad_add_kernel<__bf16>, dim3((unsigned)cdiv(tot, 256)), dim3(256), 0, s,
                        (const __bf16*)a.dqkv_pad, win_inverse, dup, n, 3 * c, (__bf16*)dqkv);
+  if (rpe.table) {
+    const int ncol = 3 * (2 * rpe.pos_bnd + 1);
+    hipLaunchKernelGGL(rpe_dtable_reduce_kernel, dim3((unsigned)cdiv((int64_t)ncol * heads, 256)), dim3(256), 0, s,
+                       a.dtab_slab, nwin, heads, (patch + 63) / 64, ncol, rpe.dtable);
+  }
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
+}
+
+extern "C" size_t ptv3_window_attn_rpe_bwd_workspace_bytes(int64_t n, int64_t n_pad, int c, int heads, int patch,
+                                                           int pos_bnd, int dtype) {
+  const int64_t blocks = (patch > 0 ? n_pad / patch : 0) * heads * ((patch + 63) / 64);
+  return ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, heads, dtype) +
+         align256((size_t)blocks * 3 * (2 * pos_bnd + 1) * sizeof(float));
+}
+
+extern "C" int ptv3_window_attn_rpe_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                                        const int32_t* win_inverse, const int32_t* grid_coord, const float* rpe_table,
+                                        int pos_bnd, void* dqkv, float* dtable, int64_t n, int64_t n_pad, int c,
+                                        int heads, int patch, float scale, int dtype, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_rpe_bwd: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_rpe_bwd: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(n_pad % patch == 0, "window_attn_rpe_bwd: n_pad=%lld is not a multiple of patch=%d", (long long)n_pad, patch);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_rpe_bwd: bad dtype %d", dtype);
+  PTV3_REQUIRE(grid_coord && rpe_table && dtable && pos_bnd >= 0, "window_attn_rpe_bwd: grid_coord, rpe_table, dtable required");
+  if (3 * (2 * pos_bnd + 1) > AB_MAX_TAB) {
+    set_error("window_attn_rpe_bwd: table column of %d entries exceeds %d", 3 * (2 * pos_bnd + 1), AB_MAX_TAB);
+    return PTV3_ERR_UNSUPPORTED;
+  }
+  PTV3_REQUIRE(workspace_bytes >= ptv3_window_attn_rpe_bwd_workspace_bytes(n, n_pad, c, heads, patch, pos_bnd, dtype),
+               "window_attn_rpe_bwd: workspace too small");
+  if (n == 0) {
+    if (hipMemsetAsync(dtable, 0, (size_t)3 * (2 * pos_bnd + 1) * heads * sizeof(float), (hipStream_t)stream) != hipSuccess)
+      return PTV3_ERR_LAUNCH;
+    return PTV3_OK;
+  }
+  return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, nullptr, (int)(n_pad / patch), dqkv, n, n_pad, c,
+                              heads, patch, scale, dtype, workspace, (hipStream_t)stream,
+                              RpeBwd{grid_coord, rpe_table, pos_bnd, dtable});
 }
 
 extern "C" int ptv3_window_attn_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,

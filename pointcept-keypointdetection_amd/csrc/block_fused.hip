@@ -856,6 +856,7 @@ extern "C" int ptv3_mlp2(const void* x, const void* w1, const float* b1, const f
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * hidden * (cin + cout),
                               ((double)m * cin + (double)hidden * (cin + cout)) * esz + (double)m * cout * (out_f32 ? 4 : esz),
                               nullptr, 0, 0.0);
+  prof_kernel(prof, PK_MLP2);
   const int rt = row_tiles(m);
   const int nto = cout <= 16 ? 1 : cout <= 32 ? 2 : 4;
   const size_t wb = ((size_t)hidden * (cin + 16 / esz) + (size_t)16 * nto * (hidden + 16 / esz)) * esz;
@@ -904,6 +905,7 @@ extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, con
   HeadArgs a{x, slab, splits, conv_bias, shortcut, g0, b0, g1, b1, wqkv, bqkv, f1, qkv, m, eps};
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * 3 * c, ((double)m * c * 6 + 3.0 * c * c) * esz, nullptr, 0, 0.0);
+  prof_kernel(prof, mode == 1 ? PK_BLOCK_HEAD : PK_BLOCK_HEAD_COOP);
   if (mode == 1) {
     const int64_t nblocks = cdiv(m, 64);
     const size_t wb = (size_t)3 * c * (c + 16 / esz) * esz;
@@ -936,6 +938,7 @@ extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wpr
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * (c + 2.0 * hidden),
                               ((double)m * c * 3 + (double)c * c + 2.0 * c * hidden) * esz, nullptr, 0, 0.0);
+  prof_kernel(prof, mode == 1 ? PK_BLOCK_TAIL : PK_BLOCK_TAIL_COOP);
   if (mode == 1) {
     TAIL_LAUNCH(a)
   } else {

@@ -9,6 +9,7 @@
 // slab order (bitwise reproducible) and finishes with the same epilogue.
 // Reference semantics: include/ptv3_hip.h (ptv3_gemm).
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
@@ -24,6 +25,7 @@ struct GemmArgs {
   const float* bias; const float* bn_scale; const float* bn_shift;
   float* slab;  // split-K partial sums [splits][m][cout] fp32 (NULL: direct epilogue)
   int64_t m; int cin; int cout; int kvol; int act; int cin_shift; int steps_per_split;
+  int debug;  // experiments only (PTV3_GEMM_DEBUG): 1 skip stores, 2 skip global loads, 4 skip the matrix core
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -87,7 +89,113 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& a, int64_t orow, 
   }
 }
 
-template <typename T, int NT>
+// ---- coalesced epilogue ---------------------------------------------------------------------------------------
+// The matrix-core result leaves a lane with 4 consecutive channels of ONE point: stored from there, a wave
+// instruction writes 16 rows x 32 bytes (bf16) - partial lines, measured at ~1 TB/s and 2/3 of a large linear's run
+// time.  Instead the tile goes through LDS (the operand buffers are free after the K loop): phase 1 applies
+// bias / folded BN / activation in registers and parks the values as T; phase 2 re-reads them row-contiguously,
+// 16 bytes per lane, adds the (indexed) residual read the same way and stores whole 128+ byte row segments.
+template <typename T> struct Chunk16;   // 16 bytes of T as floats
+template <> struct Chunk16<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float* o) { f32x4 v = *reinterpret_cast<const f32x4*>(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+  static __device__ __forceinline__ void store(float* p, const float* o) { *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]}; }
+};
+template <> struct Chunk16<__bf16> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const __bf16* p, float* o) {
+    const s16x8 v = *reinterpret_cast<const s16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = bf16_to_f32(v[i]);
+  }
+  static __device__ __forceinline__ void store(__bf16* p, const float* o) {
+    const s16x4 lo = pack4<__bf16>(o[0], o[1], o[2], o[3]), hi = pack4<__bf16>(o[4], o[5], o[6], o[7]);
+    *reinterpret_cast<s16x8*>(p) = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+};
+
+// The per-channel epilogue vectors of one accumulator fragment (channels ch0..ch0+3; cout % 4 == 0 on this path), as
+// three 16-byte loads.  All fragments' vectors are fetched back to back BEFORE any is used: one memory round trip.
+// (Fetched one channel at a time inside the value loop - the first form of this epilogue - every element paid its
+// own s_waitcnt vmcnt(0): ~60 dependent round trips per wave, 2/3 of a short-K linear's run time.)
+struct EpiVec { f32x4 bias, scale, shift; };
+__device__ __forceinline__ EpiVec load_epi(const GemmArgs& a, int ch0) {
+  EpiVec e{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  if (ch0 < a.cout) {
+    if (a.bias) e.bias = *reinterpret_cast<const f32x4*>(a.bias + ch0);
+    if (a.bn_scale) {
+      e.scale = *reinterpret_cast<const f32x4*>(a.bn_scale + ch0);
+      e.shift = *reinterpret_cast<const f32x4*>(a.bn_shift + ch0);
+    }
+  }
+  return e;
+}
+
+// phase 1 for one accumulator fragment: channels ch0..ch0+3 of tile row `rl` -> sOut[rl][cl..cl+3]
+template <typename T>
+__device__ __forceinline__ void stage_values(const GemmArgs& a, T* sOut, int os, int rl, int cl, const EpiVec& e,
+                                             f32x4 acc) {
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = apply_act((acc[r] + e.bias[r]) * e.scale[r] + e.shift[r], a.act);
+  *reinterpret_cast<typename Vec4<T>::type*>(sOut + (size_t)rl * os + cl) = pack4<T>(v[0], v[1], v[2], v[3]);
+}
+
+// phase 2: `rows` x `bn` tile in sOut (row stride os) -> out / out2, whole row segments, 16 bytes per lane.
+// Row lookups, residual loads and stores each go out in batches of UB: loads and stores share one in-order counter
+// (s_waitcnt vmcnt), so a lookup issued after a store would wait for that store to be acknowledged - per iteration.
+template <typename T>
+__device__ __forceinline__ void store_tile(const GemmArgs& a, const T* sOut, int os, int rows, int bn, int64_t row0,
+                                           int n0, int tid, int nthreads) {
+  constexpr int N = Chunk16<T>::N;
+  constexpr int UB = 8;
+  const int cpr = bn / N;
+  const int total = rows * cpr;
+  T* out = reinterpret_cast<T*>(a.out);
+  T* out2 = reinterpret_cast<T*>(a.out2);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  for (int e0 = tid; e0 < total; e0 += nthreads * UB) {
+    int64_t orow[UB];
+    int col[UB], rl[UB];
+    bool ok[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int e = e0 + u * nthreads;
+      rl[u] = e / cpr;
+      col[u] = n0 + (e - rl[u] * cpr) * N;
+      const int64_t prow = row0 + rl[u];
+      ok[u] = e < total && prow < a.m && col[u] < a.cout;
+      orow[u] = ok[u] ? (a.row_order ? (int64_t)a.row_order[prow] : prow) : 0;
+    }
+    float r[UB][N];
+    if (res) {
+      int64_t rrow[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) rrow[u] = (ok[u] && a.res_index) ? (int64_t)a.res_index[orow[u]] : orow[u];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (ok[u]) Chunk16<T>::load(res + rrow[u] * a.cout + col[u], r[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (!ok[u]) continue;
+      float v[N];
+      Chunk16<T>::load(sOut + (size_t)rl[u] * os + (col[u] - n0), v);
+      if (res) {
+        if (out2) Chunk16<T>::store(out + orow[u] * a.cout + col[u], v);
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] += r[u][i];
+        Chunk16<T>::store((out2 ? out2 : out) + orow[u] * a.cout + col[u], v);
+      } else {
+        Chunk16<T>::store(out + orow[u] * a.cout + col[u], v);
+      }
+    }
+  }
+}
+
+// GATHER: rows of x come through the neighbour table (sparse convolution); a separate instantiation, so the dense
+// linear carries none of the index arithmetic and the two show up under their own names in rocprofv3 / PMC tables
+template <typename T, int NT, bool GATHER>
 __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   constexpr int BN = 16 * NT;  // output channels per workgroup
   typedef Frag<T> F;
@@ -98,8 +206,11 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   constexpr int CPR = BK / E;        // 16-byte chunks per row (8)
   constexpr int A_LOADS = (GM_BM * CPR) / GM_THREADS;  // 2
   constexpr int B_LOADS = (BN * CPR) / GM_THREADS;     // NT/2
-  __shared__ __attribute__((aligned(16))) T sA[GM_BM * LS];
-  __shared__ __attribute__((aligned(16))) T sB[BN * LS];
+  constexpr int OS = BN + 16 / (int)sizeof(T);  // staged output tile row stride (elements): +16 bytes
+  constexpr int SM_OPER = (GM_BM + BN) * LS, SM_OUT = GM_BM * OS;
+  __shared__ __attribute__((aligned(16))) T smem_all[SM_OPER > SM_OUT ? SM_OPER : SM_OUT];
+  T* sA = smem_all;
+  T* sB = smem_all + GM_BM * LS;
 
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
@@ -144,7 +255,7 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
       if (arow[u] >= 0 && kk < ktot) {
         int64_t src = arow[u];
         int c = kk;
-        if (a.nbr) {
+        if constexpr (GATHER) {
           int d = a.cin_shift >= 0 ? (kk >> a.cin_shift) : (kk / a.cin);
           c = kk - d * a.cin;
           src = a.nbr[arow[u] * a.kvol + d];
@@ -189,6 +300,17 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   }
 
   // ---- epilogue: lane owns point (16*wave + li), channels n0 + 16j + 4g .. +3
+  if (!a.slab && (a.cout % Chunk16<T>::N) == 0) {
+    // whole rows of the tile through LDS (the operand tiles are dead: the K loop ended on a barrier)
+    EpiVec ev[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ev[j] = load_epi(a, n0 + 16 * j + 4 * g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) stage_values<T>(a, smem_all, OS, 16 * wave + li, 16 * j + 4 * g, ev[j], acc[j]);
+    __syncthreads();
+    store_tile<T>(a, smem_all, OS, GM_BM, BN, row0, n0, tid, GM_THREADS);
+    return;
+  }
   const int64_t prow = row0 + 16 * wave + li;
   if (prow >= a.m) return;
   const int64_t orow = a.row_order ? (int64_t)a.row_order[prow] : prow;
@@ -228,7 +350,7 @@ constexpr int GB_BM = 128;
 constexpr int GB_THREADS = 256;
 constexpr int GB_MAX_KVOL = 27;
 
-template <typename T, int WM, int WN, int BN>
+template <typename T, int WM, int WN, int BN, bool GATHER>
 __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
@@ -249,11 +371,14 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int wr = wave / WN, wc = wave % WN;
-  const unsigned ntm = gridDim.x;
-  // XCD-aware order: consecutive row tiles (neighbouring points: their gathers share rows in L2) on one XCD
-  const unsigned tile_m = xcd_remap(blockIdx.x, ntm);
+  // 1-D grid, channel tile fastest inside a row tile, consecutive logical ids on one XCD: the column tiles of one
+  // row tile run together on one XCD (its x rows come out of that L2 once, and the tile's output rows are written
+  // whole - 256-byte pieces at a row stride left to different moments cost the memory side its write locality)
+  const unsigned ntn = (a.cout + BN - 1) / BN;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned tile_m = logical / ntn;
   const int64_t row0 = (int64_t)tile_m * GB_BM;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = (int)(logical % ntn) * BN;
   const int ktot = a.kvol * a.cin;
   const int nsteps = (ktot + BK - 1) / BK;
 
@@ -266,7 +391,7 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
     const int64_t r = row0 + r0 + 32 * u;
     xrow[u] = r < a.m ? (a.row_order ? (int64_t)a.row_order[r] : r) : -1;
   }
-  if (a.nbr) {
+  if constexpr (GATHER) {
     // neighbour rows of the tile's points -> LDS (row-major [point][kvol])
     for (int e = tid; e < GB_BM * a.kvol; e += GB_THREADS) {
       const int pr = e / a.kvol, d = e - pr * a.kvol;
@@ -283,7 +408,7 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
     const int kk = step * BK + E * c;
     const bool kin = kk < ktot;
     int d = 0, cc = kk;
-    if (a.nbr) {
+    if constexpr (GATHER) {
       d = a.cin_shift >= 0 ? (kk >> a.cin_shift) : (kk / a.cin);
       cc = kk - d * a.cin;
     }
@@ -291,14 +416,14 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
     for (int u = 0; u < X_LOADS; ++u) {
       rx[u] = F::zero();
       int64_t src = xrow[u];
-      if (a.nbr && kin) src = sNbr[(r0 + 32 * u) * a.kvol + d];
-      if (kin && src >= 0) rx[u] = *reinterpret_cast<const FR*>(x + src * a.cin + cc);
+      if (GATHER && kin) src = sNbr[(r0 + 32 * u) * a.kvol + d];
+      if (kin && src >= 0 && !(a.debug & 2)) rx[u] = *reinterpret_cast<const FR*>(x + src * a.cin + cc);
     }
 #pragma unroll
     for (int u = 0; u < W_LOADS; ++u) {
       rw[u] = F::zero();
       const int o = n0 + r0 + 32 * u;
-      if (kin && o < a.cout) rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
+      if (kin && o < a.cout && !(a.debug & 2)) rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
     }
   };
   auto stash = [&](int buf) {
@@ -346,12 +471,29 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
 #pragma unroll
       for (int m = 0; m < MI; ++m)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[m][j] = F::mma(wf[j], xf[m], acc[m][j]);  // D[channel 4g+r][point li]
+        for (int j = 0; j < NJ; ++j)
+          if (!(a.debug & 4)) acc[m][j] = F::mma(wf[j], xf[m], acc[m][j]);  // D[channel 4g+r][point li]
     }
     __syncthreads();
   }
+  if (a.debug & 1) return;
 
   // ---- epilogue: lane owns point (16 (MI wr + m) + li), channels n0 + 16 (NJ wc + j) + 4g .. +3
+  if ((a.cout % Chunk16<T>::N) == 0) {
+    constexpr int OS = BN + 16 / (int)sizeof(T);
+    T* sOut = reinterpret_cast<T*>(gb_smem);   // 128 x (BN + pad) T <= the operand buffers
+    EpiVec ev[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) ev[j] = load_epi(a, n0 + (NJ * wc + j) * 16 + 4 * g);
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        stage_values<T>(a, sOut, OS, (MI * wr + m) * 16 + li, (NJ * wc + j) * 16 + 4 * g, ev[j], acc[m][j]);
+    __syncthreads();
+    store_tile<T>(a, sOut, OS, GB_BM, BN, row0, n0, tid, GB_THREADS);
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < MI; ++m) {
     const int64_t prow = row0 + (MI * wr + m) * 16 + li;
@@ -482,47 +624,67 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   int cin_shift = -1;
   if ((cin & (cin - 1)) == 0) { cin_shift = 0; while ((1 << cin_shift) < cin) ++cin_shift; }
   GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
-             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps};
+             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps, 0};
+  if (const char* dbg = getenv("PTV3_GEMM_DEBUG")) a.debug = atoi(dbg);
   hipStream_t s = (hipStream_t)stream;
-  const int nt = choose_nt(cout);
+  int nt = choose_nt(cout);
+  if (nbr && nt != 2) nt = 4;
   const int bn = 16 * nt;
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, nbr ? PROF_SUBM_CONV : PROF_LINEAR, 2.0 * m * kvol * cin * cout,
                               ((double)m * cin * (nbr ? 1 : kvol) + (double)cout * kvol * cin +
                                (double)m * cout * (1 + (res != nullptr) + (out2 != nullptr))) * esz,
                               nbr, m * kvol, 2.0 * cin * cout);
+  prof_kernel(prof, big ? (nbr ? PK_GEMM_BIG_CONV : PK_GEMM_BIG_DENSE)
+                        : nt == 2 ? (nbr ? PK_GEMM32_CONV : PK_GEMM32_DENSE) : (nbr ? PK_GEMM64_CONV : PK_GEMM64_DENSE));
   if (big) {
-    const size_t lds = (size_t)2 * (GB_BM + big_bn) * 128 + (nbr ? (size_t)GB_BM * kvol * 4 : 0);
-    dim3 bgrid((unsigned)cdiv(m, GB_BM), (unsigned)cdiv(cout, big_bn));
-#define GB_LAUNCH(T, WM_, WN_, BN_)                                                                              \
+    const size_t lds_out = (size_t)GB_BM * (big_bn * esz + 16);   // staged output tile of the coalesced epilogue
+    const size_t lds = std::max((size_t)2 * (GB_BM + big_bn) * 128 + (nbr ? (size_t)GB_BM * kvol * 4 : 0), lds_out);
+    dim3 bgrid((unsigned)(cdiv(m, GB_BM) * cdiv(cout, big_bn)));
+#define GB_LAUNCH(T, WM_, WN_, BN_, G_)                                                                          \
     do {                                                                                                         \
       static bool attr_set = false;                                                                              \
       if (!attr_set) {                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<T, WM_, WN_, BN_>),             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<T, WM_, WN_, BN_, G_>),         \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                        \
         attr_set = true;                                                                                         \
       }                                                                                                          \
-      hipLaunchKernelGGL((gemm_big_kernel<T, WM_, WN_, BN_>), bgrid, dim3(GB_THREADS), lds, s, a);               \
+      hipLaunchKernelGGL((gemm_big_kernel<T, WM_, WN_, BN_, G_>), bgrid, dim3(GB_THREADS), lds, s, a);           \
     } while (0)
-    if (dtype == PTV3_F32) { if (big_bn == 128) GB_LAUNCH(float, 2, 2, 128); else GB_LAUNCH(float, 4, 1, 64); }
-    else { if (big_bn == 128) GB_LAUNCH(__bf16, 2, 2, 128); else GB_LAUNCH(__bf16, 4, 1, 64); }
+#define GB_PICK(T)                                                                                               \
+    do {                                                                                                         \
+      if (nbr) { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, true); else GB_LAUNCH(T, 4, 1, 64, true); }          \
+      else { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, false); else GB_LAUNCH(T, 4, 1, 64, false); }            \
+    } while (0)
+    if (dtype == PTV3_F32) GB_PICK(float); else GB_PICK(__bf16);
+#undef GB_PICK
 #undef GB_LAUNCH
     prof_end(prof, s);
     PTV3_LAUNCH_CHECK();
     return PTV3_OK;
   }
   dim3 grid((unsigned)cdiv(m, GM_BM), (unsigned)cdiv(cout, bn), (unsigned)splits);
-#define GM_LAUNCH(T)                                                                                   \
+#define GM_LAUNCH(T, G)                                                                                \
   switch (nt) {                                                                                        \
-    case 2: hipLaunchKernelGGL((gemm_kernel<T, 2>), grid, dim3(GM_THREADS), 0, s, a); break;           \
-    case 4: hipLaunchKernelGGL((gemm_kernel<T, 4>), grid, dim3(GM_THREADS), 0, s, a); break;           \
-    case 6: hipLaunchKernelGGL((gemm_kernel<T, 6>), grid, dim3(GM_THREADS), 0, s, a); break;           \
-    case 8: hipLaunchKernelGGL((gemm_kernel<T, 8>), grid, dim3(GM_THREADS), 0, s, a); break;           \
-    case 12: hipLaunchKernelGGL((gemm_kernel<T, 12>), grid, dim3(GM_THREADS), 0, s, a); break;         \
-    default: hipLaunchKernelGGL((gemm_kernel<T, 16>), grid, dim3(GM_THREADS), 0, s, a); break;         \
+    case 2: hipLaunchKernelGGL((gemm_kernel<T, 2, G>), grid, dim3(GM_THREADS), 0, s, a); break;        \
+    case 4: hipLaunchKernelGGL((gemm_kernel<T, 4, G>), grid, dim3(GM_THREADS), 0, s, a); break;        \
+    case 6: hipLaunchKernelGGL((gemm_kernel<T, 6, G>), grid, dim3(GM_THREADS), 0, s, a); break;        \
+    case 8: hipLaunchKernelGGL((gemm_kernel<T, 8, G>), grid, dim3(GM_THREADS), 0, s, a); break;        \
+    case 12: hipLaunchKernelGGL((gemm_kernel<T, 12, G>), grid, dim3(GM_THREADS), 0, s, a); break;      \
+    default: hipLaunchKernelGGL((gemm_kernel<T, 16, G>), grid, dim3(GM_THREADS), 0, s, a); break;      \
   }
-  if (dtype == PTV3_F32) { GM_LAUNCH(float) } else { GM_LAUNCH(__bf16) }
+  if (nbr) {
+    // the gathered instantiations only exist for the tile widths the policy picks (2, 4)
+    if (dtype == PTV3_F32) {
+      if (nt == 2) hipLaunchKernelGGL((gemm_kernel<float, 2, true>), grid, dim3(GM_THREADS), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<float, 4, true>), grid, dim3(GM_THREADS), 0, s, a);
+    } else {
+      if (nt == 2) hipLaunchKernelGGL((gemm_kernel<__bf16, 2, true>), grid, dim3(GM_THREADS), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<__bf16, 4, true>), grid, dim3(GM_THREADS), 0, s, a);
+    }
+  } else if (dtype == PTV3_F32) { GM_LAUNCH(float, false) } else { GM_LAUNCH(__bf16, false) }
 #undef GM_LAUNCH
+  prof_end(prof, s);   // the bracket times the GEMM launch alone (the slab reduce below is its own, tiny kernel)
   if (splits > 1 && out != nullptr) {
     GemmArgs r = a;
     r.row_order = nullptr;  // slabs are indexed by output row already
@@ -532,7 +694,6 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
     else
       hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
   }
-  prof_end(prof, s);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -6,7 +6,12 @@
 
 namespace ptv3 {
 
-struct ProfRec { int family; double flops, bytes, per_valid; hipEvent_t e0, e1; int slot; };
+struct ProfRec { int family; double flops, bytes, per_valid; hipEvent_t e0, e1; int slot; int kernel; };
+static const char* const g_kernel_names[PK_KERNELS] = {
+    "gemm_kernel<64ch> dense", "gemm_kernel<64ch> gather (sparse conv)", "gemm_kernel<32ch> dense",
+    "gemm_kernel<32ch> gather (sparse conv)", "gemm_big_kernel dense", "gemm_big_kernel gather (sparse conv)",
+    "block_head_kernel", "block_tail_kernel", "block_head_coop_kernel", "block_tail_coop_kernel", "mlp2_kernel",
+    "window_attn_full_kernel", "window_attn_kernel"};
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -34,7 +39,8 @@ static hipEvent_t get_event() {
 int prof_begin(hipStream_t s, int family, double flops, double bytes, const int32_t* nbr, int64_t nbr_count,
                double flops_per_valid) {
   if (!g_on) return -1;
-  ProfRec r{family, flops, bytes, flops_per_valid, get_event(), get_event(), -1};
+  static const int default_kernel[PROF_FAMILIES] = {PK_GEMM64_DENSE, PK_GEMM64_CONV, PK_ATTN_FULL};
+  ProfRec r{family, flops, bytes, flops_per_valid, get_event(), get_event(), -1, default_kernel[family]};
   if (nbr && g_slots && g_nslots < MAX_SLOTS) {
     r.slot = g_nslots++;
     hipLaunchKernelGGL(count_valid_kernel, dim3(512), dim3(256), 0, s, nbr, nbr_count, g_slots + r.slot);
@@ -46,6 +52,10 @@ int prof_begin(hipStream_t s, int family, double flops, double bytes, const int3
 
 void prof_end(int rec, hipStream_t s) {
   if (rec >= 0) (void)hipEventRecord(g_recs[rec].e1, s);
+}
+
+void prof_kernel(int rec, int kernel) {
+  if (rec >= 0 && kernel >= 0 && kernel < PK_KERNELS) g_recs[rec].kernel = kernel;
 }
 
 }  // namespace ptv3
@@ -66,20 +76,35 @@ extern "C" int ptv3_profile_enable(int on) {
   return PTV3_OK;
 }
 
-extern "C" int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches) {
+extern "C" int ptv3_profile_kernel_count(void) { return PK_KERNELS; }
+extern "C" const char* ptv3_profile_kernel_name(int kernel) {
+  return kernel >= 0 && kernel < PK_KERNELS ? g_kernel_names[kernel] : "";
+}
+
+static int collect(int by_kernel, int n, double* ms, double* flops, double* bytes, int64_t* launches) {
   if (hipDeviceSynchronize() != hipSuccess) { set_error("profile: synchronize failed"); return PTV3_ERR_LAUNCH; }
   std::vector<unsigned long long> slots(g_nslots > 0 ? g_nslots : 1);
   if (g_nslots > 0) (void)hipMemcpy(slots.data(), g_slots, (size_t)g_nslots * 8, hipMemcpyDeviceToHost);
-  for (int f = 0; f < PROF_FAMILIES; ++f) { ms[f] = flops[f] = bytes[f] = 0.0; launches[f] = 0; }
+  for (int f = 0; f < n; ++f) { ms[f] = flops[f] = bytes[f] = 0.0; launches[f] = 0; }
   for (auto& r : g_recs) {
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.e0, r.e1);
-    ms[r.family] += t;
-    flops[r.family] += r.slot >= 0 ? r.per_valid * (double)slots[r.slot] : r.flops;
-    bytes[r.family] += r.bytes;
-    launches[r.family] += 1;
-    g_pool.push_back(r.e0); g_pool.push_back(r.e1);
+    const int k = by_kernel ? r.kernel : r.family;
+    ms[k] += t;
+    flops[k] += r.slot >= 0 ? r.per_valid * (double)slots[r.slot] : r.flops;
+    bytes[k] += r.bytes;
+    launches[k] += 1;
   }
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_profile_collect_kernels(double* ms, double* flops, double* bytes, int64_t* launches) {
+  return collect(1, PK_KERNELS, ms, flops, bytes, launches);   // does not reset: call before ptv3_profile_collect
+}
+
+extern "C" int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches) {
+  if (int rc = collect(0, PROF_FAMILIES, ms, flops, bytes, launches)) return rc;
+  for (auto& r : g_recs) { g_pool.push_back(r.e0); g_pool.push_back(r.e1); }
   g_recs.clear();
   if (g_slots) (void)hipMemset(g_slots, 0, (size_t)MAX_SLOTS * 8);
   g_nslots = 0;

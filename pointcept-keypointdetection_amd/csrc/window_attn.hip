@@ -483,16 +483,19 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
         if constexpr (!SUM_MFMA) ps += (p0 + p1) + (p2 + p3);
         pf[kt] = pack4<T>(p0, p1, p2, p3);
       }
+      // P V and the row sums in 32-key steps (bf16: v_mfma_f32_16x16x32_bf16, half the matrix-core issues of the
+      // 16-key form; the 32 keys of a step are the two 16-key score tiles side by side, in registers as they are)
       if constexpr (SUM_MFMA) {
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) lacc[t] = mma16<T>(ones, pf[kt], lacc[t]);
+        for (int kp = 0; kp < 2; ++kp) lacc[t] = mma16x2<T>(ones, ones, pf[2 * kp], pf[2 * kp + 1], lacc[t]);
       } else {
         lacc[t][0] += ps;
       }
 #pragma unroll
       for (int c = 0; c < ND; ++c)
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) o[t][c] = mma16<T>(vf[c][kt], pf[kt], o[t][c]);
+        for (int kp = 0; kp < 2; ++kp)
+          o[t][c] = mma16x2<T>(vf[c][2 * kp], vf[c][2 * kp + 1], pf[2 * kp], pf[2 * kp + 1], o[t][c]);
     }
   };
 
@@ -587,6 +590,8 @@ static void full_config(int64_t pairs, int K, int qt_max, size_t lds, int* waves
   *qt_out = bq;
 }
 
+static bool g_last_launch_tiled = false;   // which kernel the last launch_window_attn chose (profiling tag only)
+
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
                               int K, int nwin, float scale, const float* rpe, hipStream_t s,
@@ -600,6 +605,7 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
     set_error("window_attn_rpe: window of %d keys does not fit the resident-window kernel", K);
     return PTV3_ERR_UNSUPPORTED;
   }
+  g_last_launch_tiled = lds_full > 160 * 1024;
   if (lds_full <= 160 * 1024) {
     int waves, qt;
     full_config(nwin * (int64_t)H, K, WaCfg<T, ND>::QT, lds_full, &waves, &qt);
@@ -651,6 +657,7 @@ static int window_attn_fwd_impl(const void* qkv, const int32_t* win_order, const
   }
   if (dtype == PTV3_F32) { WA_CASE(float) } else { WA_CASE(__bf16) }
 #undef WA_CASE
+  prof_kernel(prof, g_last_launch_tiled ? PK_ATTN_TILED : PK_ATTN_FULL);
   prof_end(prof, s);
   return rc;
 }
@@ -715,6 +722,7 @@ extern "C" int ptv3_window_attn_rpe_fwd(const void* qkv, const int32_t* win_orde
   }
   if (dtype == PTV3_F32) { WAR_CASE(float) } else { WAR_CASE(__bf16) }
 #undef WAR_CASE
+  prof_kernel(prof, PK_ATTN_FULL);
   prof_end(prof, s);
   return rc;
 }

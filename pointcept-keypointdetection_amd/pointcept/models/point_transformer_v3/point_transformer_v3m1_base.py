@@ -133,25 +133,32 @@ class SerializedAttention(PointModule):
             return None
         return self.get_padding_and_inverse(point)[2]
 
+    def _check_attn_drop(self):
+        p_drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else float(self.attn_drop)
+        if p_drop > 0.0:  # the reference drops attention probabilities (:203, :211); no such kernel here
+            raise NotImplementedError("SerializedAttention: attn_drop > 0 has no training kernel on the HIP path "
+                                      "(0.0 in every PTv3 config of the reference)")
+
     def attention_core(self, point, qkv):
         """gather -> softmax(QK^T)V -> scatter (:188-216) in one kernel."""
         K = self.resolve_patch_size(point)
         wo, wi = self.window_maps(point)
         bias = None
         if self.enable_rpe:
-            _no_training(self)  # the backward kernel has no bias-gradient path yet
             gkey = "_grid_coord_i32"
             if gkey not in point.keys():
                 point[gkey] = point.grid_coord.int().contiguous()
+            if self.training:
+                self._check_attn_drop()
+                return A.window_attention_rpe(qkv, self.rpe.rpe_table, wo, wi, point[gkey], self.num_heads, K,
+                                              self.scale, self.rpe.pos_bnd)
             out = ops.window_attention_rpe(qkv, wo, wi, self.num_heads, K, self.scale, point[gkey],
                                            self.rpe.rpe_table.detach().float().contiguous(), self.rpe.pos_bnd)
             if out is not None:
                 return out
             bias = self.rpe(self.get_rel_pos(point, wo.long()))
         if self.training:
-            p_drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else float(self.attn_drop)
-            if p_drop > 0.0:  # the reference drops attention probabilities (:203, :211); no such kernel here yet
-                raise NotImplementedError("SerializedAttention: attn_drop > 0 has no training kernel on the HIP path")
+            self._check_attn_drop()
             return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, self.window_cu(point))
         cu = self.window_cu(point)
         if cu is not None:
@@ -285,7 +292,8 @@ class Block(PointModule):
     def _train_fusable(self):
         mlp = self.mlp[0]
         drops = [self.attn.proj_drop, mlp.drop] + ([self.attn.attn_drop] if isinstance(self.attn.attn_drop, nn.Dropout) else [])
-        return (self._fusable() and isinstance(mlp.act, nn.GELU) and not self.attn.enable_rpe
+        flash_drop = (not isinstance(self.attn.attn_drop, nn.Dropout)) and float(self.attn.attn_drop) > 0.0
+        return (self._fusable() and isinstance(mlp.act, nn.GELU) and not self.attn.enable_rpe and not flash_drop
                 and all(d.p == 0.0 for d in drops) and self.cpe[0].bias is not None
                 and self.cpe[2].eps == self.norm1[0].eps == self.norm2[0].eps
                 and isinstance(self.drop_path[0], (DropPath, nn.Identity)))

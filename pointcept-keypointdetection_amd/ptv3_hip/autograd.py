@@ -231,6 +231,30 @@ class WindowAttentionFn(Function):
                 None, None, None, None, None, None)
 
 
+class WindowAttentionRpeFn(Function):
+    """Window attention with the RPE bias looked up in the kernel (:29-48, :196-204): gradients for qkv AND the bias
+    table (each (query, key) pair's dS goes to the three table entries it read)."""
+
+    @staticmethod
+    def forward(ctx, qkv, rpe_table, win_order, win_inverse, grid_coord, heads, patch, scale, pos_bnd):
+        qkv = qkv.contiguous()
+        table = rpe_table.detach().float().contiguous()
+        out = ops.window_attention_rpe(qkv, win_order, win_inverse, heads, patch, scale, grid_coord, table, pos_bnd)
+        if out is None:
+            raise NotImplementedError("training with enable_rpe: the window does not fit the resident-window kernel")
+        ctx.save_for_backward(qkv, out, win_order, win_inverse, grid_coord, table)
+        ctx.cfg = (heads, patch, scale, pos_bnd, rpe_table.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, win_order, win_inverse, grid_coord, table = ctx.saved_tensors
+        heads, patch, scale, pos_bnd, pdtype = ctx.cfg
+        dqkv, dtable = ops.window_attention_rpe_bwd(qkv, out, dout.contiguous(), win_order, win_inverse, heads, patch,
+                                                    scale, grid_coord, table, pos_bnd)
+        return dqkv, dtable.to(pdtype), None, None, None, None, None, None, None
+
+
 class SegmentMaxFn(Function):
     """torch_scatter.segment_csr(feat[indices], idx_ptr, reduce="max") (:416-421) over serialized-order runs."""
 
@@ -290,6 +314,10 @@ def activation(x, act):
 
 def window_attention(qkv, win_order, win_inverse, heads, patch, scale, cu=None):
     return WindowAttentionFn.apply(qkv, win_order, win_inverse, heads, patch, scale, cu)
+
+
+def window_attention_rpe(qkv, rpe_table, win_order, win_inverse, grid_coord, heads, patch, scale, pos_bnd):
+    return WindowAttentionRpeFn.apply(qkv, rpe_table, win_order, win_inverse, grid_coord, heads, patch, scale, pos_bnd)
 
 
 def segment_max(feat, order0, seg_start, n_out):

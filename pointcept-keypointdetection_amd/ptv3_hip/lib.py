@@ -68,6 +68,9 @@ SIGNATURES = {
                                      c_size_t, P]),
     "ptv3_window_attn_varlen_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
                                             c_int, P, c_size_t, P]),
+    "ptv3_window_attn_rpe_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int]),
+    "ptv3_window_attn_rpe_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, c_int,
+                                         c_float, c_int, P, c_size_t, P]),
     "ptv3_adamw_entry_bytes": (c_size_t, []),
     "ptv3_adamw_chunk": (c_int, []),
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
@@ -79,6 +82,9 @@ SIGNATURES = {
     "ptv3_keypoint_aggregate": (c_int, [P, P, P, c_int, c_int, P, P, c_int, c_float, P, P, P]),
     "ptv3_profile_enable": (c_int, [c_int]),
     "ptv3_profile_collect": (c_int, [P, P, P, P]),
+    "ptv3_profile_kernel_count": (c_int, []),
+    "ptv3_profile_kernel_name": (c_char_p, [c_int]),
+    "ptv3_profile_collect_kernels": (c_int, [P, P, P, P]),
     "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "ptv3_grouping_forward": (c_int, [c_int, c_int, c_int, P, P, P, P]),
     "ptv3_grouping_backward": (c_int, [c_int, c_int, c_int, P, P, P, P]),

@@ -600,6 +600,33 @@ def window_attention_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, s
     return dqkv
 
 
+def window_attention_rpe_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, scale, grid_coord, rpe_table,
+                             pos_bnd):
+    """-> (dqkv (n, 3c), dtable (3*(2*pos_bnd+1), heads) fp32) of window_attention_rpe."""
+    _chk(qkv, "qkv", _F, 2)
+    _chk(out, "out", qkv.dtype, 2)
+    _chk(dout, "dout", qkv.dtype, 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    _chk(grid_coord, "grid_coord", torch.int32, 2)
+    _chk(rpe_table, "rpe_table", torch.float32, 2)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    n_pad = win_order.shape[0]
+    if out.shape != (n, c) or dout.shape != (n, c) or win_inverse.shape[0] != n or tuple(grid_coord.shape) != (n, 3) \
+            or tuple(rpe_table.shape) != (3 * (2 * pos_bnd + 1), heads):
+        raise RuntimeError("window_attention_rpe_bwd: shape mismatch")
+    dqkv = torch.empty_like(qkv)
+    dtable = torch.empty_like(rpe_table)
+    nb = lib.ptv3_window_attn_rpe_bwd_workspace_bytes(n, n_pad, c, int(heads), int(patch), int(pos_bnd), _dt(qkv))
+    ws = _ws(nb, qkv.device)
+    lib.check(lib.ptv3_window_attn_rpe_bwd(_p(qkv), _p(out), _p(dout), _p(win_order), _p(win_inverse), _p(grid_coord),
+                                           _p(rpe_table), int(pos_bnd), _p(dqkv), _p(dtable), n, n_pad, c, int(heads),
+                                           int(patch), float(scale), _dt(qkv), _p(ws), nb, _stream()),
+              "ptv3_window_attn_rpe_bwd")
+    return dqkv, dtable
+
+
 # ---------------------------------------------------------------------------------------------
 # GridSample (before the model)
 # ---------------------------------------------------------------------------------------------
@@ -677,6 +704,17 @@ FAMILIES = ("linear", "subm_conv", "window_attn")
 
 def profile_enable(on=True):
     lib.check(lib.ptv3_profile_enable(int(on)), "ptv3_profile_enable")
+
+
+def profile_collect_kernels():
+    """{kernel name: dict(ms, flops, bytes, launches)} per KERNEL (one launch per bracket); call before
+    profile_collect(), which resets the records."""
+    n = int(lib.ptv3_profile_kernel_count())
+    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    la = (ctypes.c_int64 * n)()
+    lib.check(lib.ptv3_profile_collect_kernels(ms, fl, by, la), "ptv3_profile_collect_kernels")
+    return {lib.ptv3_profile_kernel_name(i).decode(): dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i]))
+            for i in range(n) if la[i]}
 
 
 def profile_collect():

@@ -239,3 +239,76 @@ def test_train_step_vs_reference_golden(dev, golden_dir):
     for n, b in model.named_buffers():
         if "running" in n:
             assert _rel(b, torch.from_numpy(g["buf_" + n])) < 1e-4, n
+
+
+def test_rpe_attention_backward_vs_autograd(dev):
+    """ptv3_window_attn_rpe_bwd: dqkv and the gradient of the relative-position table against torch autograd over the
+    restated vanilla attention with RPE (point_transformer_v3m1_base.py:29-48, 196-204)."""
+    from ptv3_hip import autograd as A, ops
+    from oracle import sfc, ptv3 as O
+    import ptv3_scenes as S
+    C, H, K = 32, 2, 64
+    data = S.make_batch([300, 200], in_channels=4, extent=24, seed=9)
+    off = data["offset"].numpy()
+    batch = torch.arange(2).repeat_interleave(torch.tensor([300, 200])).numpy()
+    _, order, inverse, _ = sfc.serialization(data["grid_coord"].numpy(), batch, ["z", "hilbert"])
+    Kp = sfc.patch_size_for(off, K)
+    pad, unpad, _ = sfc.pad_plan(off, Kp)
+    g = torch.Generator().manual_seed(4)
+    n = 500
+    qkv = torch.randn(n, 3 * C, generator=g)
+    pos_bnd = int((4 * K) ** (1 / 3) * 2)
+    table = torch.randn(3 * (2 * pos_bnd + 1), H, generator=g) * 0.5
+    dout = torch.randn(n, C, generator=g)
+    # reference: autograd through the oracle's statements
+    q, t = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    o = torch.from_numpy(order[1])[torch.from_numpy(pad)]
+    inv = torch.from_numpy(unpad)[torch.from_numpy(inverse[1])]
+    x = q[o]
+    qq, kk, vv = x.reshape(-1, Kp, 3, H, C // H).permute(2, 0, 3, 1, 4).unbind(dim=0)
+    attn = (qq * (C // H) ** -0.5) @ kk.transpose(-2, -1) + O.rpe_bias(t, data["grid_coord"][o], Kp, K, H)
+    ref = (torch.softmax(attn, dim=-1) @ vv).transpose(1, 2).reshape(-1, C)[inv]
+    ref.backward(dout)
+    wo, wi = ops.window_maps(torch.from_numpy(order[1]).to(dev), torch.from_numpy(inverse[1]).to(dev),
+                             torch.from_numpy(pad).to(dev), torch.from_numpy(unpad).to(dev))
+    qd, td = qkv.to(dev).requires_grad_(True), table.to(dev).requires_grad_(True)
+    out = A.window_attention_rpe(qd, td, wo, wi, data["grid_coord"].int().to(dev).contiguous(), H, Kp,
+                                 (C // H) ** -0.5, pos_bnd)
+    out.backward(dout.to(dev))
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-4
+    assert _rel(qd.grad, q.grad) < 1e-4
+    assert _rel(td.grad, t.grad) < 1e-4
+
+
+def test_train_step_with_rpe_vs_oracle_autograd(dev):
+    """enable_rpe=True in training (configs/s3dis/semseg-pt-v3m1-1-rpe.py style): every parameter gradient, the
+    rpe tables included, against torch autograd over the oracle."""
+    from oracle import ptv3 as O
+    import ptv3_scenes as S
+    cfg = dict(TINY_CFG, drop_path=0.0, enable_rpe=True)
+    torch.manual_seed(77)
+    model = _build(cfg, hidden_dim=32)
+    _perturb_stats(model)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("rpe_table"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    data = S.make_batch([800, 500], in_channels=4, extent=48, seed=23, with_target=6)
+    orc = O.OffsetKeypointOracle(cfg, sd, training=True)
+    torch.manual_seed(5)
+    ref = orc.forward(data)
+    ref["loss"].backward()
+    ref_grads = {k: v.grad for k, v in orc.named_parameters()}
+    model = model.to(dev).train()
+    torch.manual_seed(5)
+    out = model({k: v.to(dev) for k, v in data.items()})
+    out["loss"].backward()
+    assert abs(out["loss"].item() - ref["loss"].item()) < 1e-4
+    tables = [n for n, _ in model.named_parameters() if n.endswith("rpe_table")]
+    assert len(tables) == 10 and all(ref_grads[n].abs().max() > 0 for n in tables)
+    gmax = max(v.abs().max().item() for v in ref_grads.values())
+    worst = max(((n, _rel(p.grad, ref_grads[n], 1e-3 * gmax)) for n, p in model.named_parameters()),
+                key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst
