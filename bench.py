@@ -75,10 +75,17 @@ def allreduce_probe(device, nbytes, reps=5):
             "busbw_GBps": round(2 * (world - 1) / world * nbytes / dt / 1e9, 2), "ranks": world}
 
 
-def pmc_traffic(args, kernel_family):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/measure_round.sh ->
-    profiles/<round>/pmc_traffic.json), if they were taken on this workload.  linear and subm_conv are the
-    same kernel (gemm_kernel), so the PMC figure covers both families."""
+def _pmc_label(kernel, dtype):
+    """bench.py's kernel name -> the label tools/kernel_names.py gives the same kernel in the PMC / trace summaries"""
+    dt = "bf16" if dtype == "bf16" else "f32"
+    for tag in ("64ch", "32ch"):
+        kernel = kernel.replace(f"gemm_kernel<{tag}>", f"gemm_kernel<{dt},{tag}>")
+    return kernel.replace("gemm_big_kernel ", f"gemm_big_kernel<{dt},128ch> ")
+
+
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/measure_round.sh ->
+    profiles/<round>/pmc_traffic.json), if they were taken on this workload."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
     if not files:
@@ -87,14 +94,19 @@ def pmc_traffic(args, kernel_family):
     w = data.get("workload", {})
     if (w.get("points"), w.get("scenes"), w.get("dtype"), w.get("kind")) != (args.points, args.scenes, args.dtype, args.kind):
         return None, None
-    key = kernel_family.split(" ")[0]   # "gemm_kernel<64ch> dense" -> the rocprof kernel name prefix
-    key = {"gemm_kernel<64ch>": "gemm_kernel<bf16,64ch>", "gemm_kernel<32ch>": "gemm_kernel<bf16,32ch>"}.get(key, key)
-    k = data["kernels"].get(key)
-    if not k:
+    want = _pmc_label(kernel, args.dtype)
+    hits = [v for k, v in data["kernels"].items()
+            if k.replace(",pd4", "") == want or (want.startswith("window_attn_full_kernel") and k.startswith(want))]
+    if not hits:
         return None, None
-    return k["hbm_bytes_per_launch"], {"source": os.path.relpath(files[-1], ROOT), "kernel": key,
-                                       "hbm_mb_per_step": round(k["hbm_bytes_per_step"] / 1e6, 1),
-                                       "launches_per_step": k["launches_per_step"]}
+    step = sum(h["hbm_bytes_per_step"] for h in hits)
+    launches = sum(h["launches_per_step"] for h in hits)
+    detail = {"source": os.path.relpath(files[-1], ROOT), "kernel": want, "hbm_mb_per_step": round(step / 1e6, 1),
+              "launches_per_step": launches}
+    raw = [h.get("fetch_bytes_per_step_raw") for h in hits]
+    if all(r is not None for r in raw):   # gathered reads: FETCH_SIZE x1 .. x2 (see tools/pmc_traffic.py)
+        detail["hbm_mb_per_step_low"] = round((step - sum(raw)) / 1e6, 1)
+    return step / max(launches, 1e-9), detail
 
 
 def pmc_sq():
@@ -107,7 +119,7 @@ def pmc_sq():
     data = json.load(open(files[-1])).get("kernels", {})
     keep = ("mfma_util", "share_issuing", "share_issue_stall", "share_parked")
     out = {k: {f: v[f] for f in keep if f in v} for k, v in data.items()
-           if k in ("window_attn_full_kernel", "gemm_kernel<bf16,64ch>")}
+           if k.startswith(("window_attn_full_kernel", "gemm_kernel<bf16,64ch", "gemm_big_kernel", "block_"))}
     return {"source": os.path.relpath(files[-1], ROOT),
             "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)", **out} if out else None
 

@@ -107,13 +107,24 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
   const int li = lane & 15, g = lane >> 4;
   const T* w = reinterpret_cast<const T*>(a.wqkv);
   int ldc = C;
+  // The per-channel vectors (two LayerNorm affines, qkv bias, conv bias) live in LDS next to the weights: read from
+  // global inside the row loop, each read that follows a store waits for that store to be acknowledged (loads and
+  // stores retire through one in-order counter) - LDS reads do not.
+  float* sVec = reinterpret_cast<float*>(head_smem + (WLDS ? (size_t)3 * C * (C + WPad<T>::V) * sizeof(T) : 0));
+  const float *vg0 = sVec, *vb0 = sVec + C, *vg1 = sVec + 2 * C, *vb1 = sVec + 3 * C, *vbq = sVec + 4 * C,
+              *vcb = sVec + 7 * C;
+  for (int i = threadIdx.x; i < C; i += 256) {
+    sVec[i] = a.g0[i]; sVec[C + i] = a.b0[i]; sVec[2 * C + i] = a.g1[i]; sVec[3 * C + i] = a.b1[i];
+    sVec[7 * C + i] = a.conv_bias ? a.conv_bias[i] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 3 * C; i += 256) sVec[4 * C + i] = a.bqkv[i];
   if (WLDS) {   // the 3C x C qkv weight resident in LDS for all row blocks of this workgroup
     ldc = C + WPad<T>::V;
     T* sW = reinterpret_cast<T*>(head_smem);
     stage_matrix<T>(sW, w, 3 * C, C, ldc);
-    __syncthreads();
     w = sW;
   }
+  __syncthreads();
   const int64_t nblocks = (a.m + 63) / 64;
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
   const int64_t row = (blk * 4 + wave) * 16 + li;
@@ -127,7 +138,7 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
   for (int j = 0; j < NT; ++j) {
     const int ch = 16 * j + 4 * g;
     if (a.slab) {
-      f32x4 acc = *reinterpret_cast<const f32x4*>(a.conv_bias + ch);
+      f32x4 acc = *reinterpret_cast<const f32x4*>(vcb + ch);
       for (int z = 0; z < a.splits; ++z)
         acc += *reinterpret_cast<const f32x4*>(a.slab + ((int64_t)z * a.m + rc) * C + ch);
 #pragma unroll
@@ -144,7 +155,7 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ch = 16 * j + 4 * g;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g0 + ch), bt = *reinterpret_cast<const f32x4*>(a.b0 + ch);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(vg0 + ch), bt = *reinterpret_cast<const f32x4*>(vb0 + ch);
     float s[4];
     unpack4<T>(*reinterpret_cast<const V4*>(sc + rc * C + ch), s);
 #pragma unroll
@@ -155,7 +166,7 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ch = 16 * j + 4 * g;
-    const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g1 + ch), bt = *reinterpret_cast<const f32x4*>(a.b1 + ch);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(vg1 + ch), bt = *reinterpret_cast<const f32x4*>(vb1 + ch);
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[j][r] = round_to<T>((v[j][r] - mean) * rstd * gm[r] + bt[r]);
   }
@@ -182,7 +193,7 @@ __global__ void __launch_bounds__(256) block_head_kernel(HeadArgs a) {
     for (int jj = 0; jj < 4; ++jj)
       if (o0 + jj < OT && valid) {
         const int ch = 16 * (o0 + jj) + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(a.bqkv + ch);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(vbq + ch);
         *reinterpret_cast<V4*>(qkv + row * (3 * C) + ch) =
             pack4<T>(acc[jj][0] + b[0], acc[jj][1] + b[1], acc[jj][2] + b[2], acc[jj][3] + b[3]);
       }
@@ -212,17 +223,25 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
   const T* w1 = reinterpret_cast<const T*>(a.w1);
   const T* w2 = reinterpret_cast<const T*>(a.w2);
   int ldc = C, ldh = a.hidden;   // row strides of (wproj, w1) and of w2
+  // per-channel vectors in LDS (see block_head_kernel): no global read between the stores of the row loop
+  const float *vbp = a.bproj, *vg2 = a.g2, *vb2 = a.b2, *vbias1 = a.bias1, *vbias2 = a.bias2;
   if (WLDS) {
     ldc = C + WPad<T>::V;
     ldh = a.hidden + WPad<T>::V;
     T* sWp = reinterpret_cast<T*>(tail_smem);
     T* sW1 = sWp + C * ldc;
     T* sW2 = sW1 + a.hidden * ldc;
+    float* sVec = reinterpret_cast<float*>(sW2 + C * ldh);   // 16-byte aligned: every part above is a multiple of 16 bytes
     stage_matrix<T>(sWp, wp, C, C, ldc);
     stage_matrix<T>(sW1, w1, a.hidden, C, ldc);
     stage_matrix<T>(sW2, w2, C, a.hidden, ldh);
+    for (int i = threadIdx.x; i < C; i += 256) {
+      sVec[i] = a.bproj[i]; sVec[C + i] = a.g2[i]; sVec[2 * C + i] = a.b2[i]; sVec[3 * C + i] = a.bias2[i];
+    }
+    for (int i = threadIdx.x; i < a.hidden; i += 256) sVec[4 * C + i] = a.bias1[i];
     __syncthreads();
     wp = sWp; w1 = sW1; w2 = sW2;
+    vbp = sVec; vg2 = sVec + C; vb2 = sVec + 2 * C; vbias2 = sVec + 3 * C; vbias1 = sVec + 4 * C;
   }
   const int64_t nblocks = (a.m + 64 * RT - 1) / (64 * RT);
   for (int64_t blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -260,7 +279,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int ch = 16 * j + 4 * g;
-      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bproj + ch);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(vbp + ch);
       float s[4];
       unpack4<T>(*reinterpret_cast<const V4*>(f1 + rc[t] * C + ch), s);
 #pragma unroll
@@ -271,7 +290,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int ch = 16 * j + 4 * g;
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(a.g2 + ch), bt = *reinterpret_cast<const f32x4*>(a.b2 + ch);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(vg2 + ch), bt = *reinterpret_cast<const f32x4*>(vb2 + ch);
 #pragma unroll
       for (int r = 0; r < 4; ++r) t5[j][r] = round_to<T>((f2[t][j][r] - mean) * rstd * gm[r] + bt[r]);
     }
@@ -302,7 +321,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
         w2f[mm][j] = *reinterpret_cast<const FR*>(w2 + (16 * j + li) * ldh + h0 + KC * mm + E * g);
     f32x4 bias1[4];
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) bias1[jj] = *reinterpret_cast<const f32x4*>(a.bias1 + h0 + 16 * jj + 4 * g);
+    for (int jj = 0; jj < 4; ++jj) bias1[jj] = *reinterpret_cast<const f32x4*>(vbias1 + h0 + 16 * jj + 4 * g);
     f32x4 h[RT][4];
 #pragma unroll
     for (int t = 0; t < RT; ++t)
@@ -344,7 +363,7 @@ __global__ void __launch_bounds__(256) block_tail_kernel(TailArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int ch = 16 * j + 4 * g;
-      const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias2 + ch);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(vbias2 + ch);
       *reinterpret_cast<V4*>(out + row[t] * C + ch) =
           pack4<T>(o[t][j][0] + b[0] + f2[t][j][0], o[t][j][1] + b[1] + f2[t][j][1], o[t][j][2] + b[2] + f2[t][j][2],
                    o[t][j][3] + b[3] + f2[t][j][3]);
@@ -730,7 +749,7 @@ static int row_tiles(int64_t m) {
 
 static size_t tail_wlds_bytes(int c, int hidden, int esz) {
   const int pad = 16 / esz;
-  return ((size_t)(c + hidden) * (c + pad) + (size_t)c * (hidden + pad)) * esz;
+  return ((size_t)(c + hidden) * (c + pad) + (size_t)c * (hidden + pad)) * esz + (size_t)(4 * c + hidden) * sizeof(float);
 }
 
 template <typename T, int NT, int RT>
@@ -908,7 +927,7 @@ extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, con
   prof_kernel(prof, mode == 1 ? PK_BLOCK_HEAD : PK_BLOCK_HEAD_COOP);
   if (mode == 1) {
     const int64_t nblocks = cdiv(m, 64);
-    const size_t wb = (size_t)3 * c * (c + 16 / esz) * esz;
+    const size_t wb = (size_t)3 * c * (c + 16 / esz) * esz + (size_t)8 * c * sizeof(float);  // weights + vectors
     const dim3 grid_l((unsigned)std::min<int64_t>(nblocks, 4 * 256)), block(256);
     if (dtype == PTV3_F32) {
       if (c == 32) hipLaunchKernelGGL((block_head_kernel<float, 2, true>), grid_l, block, wb, s, a);

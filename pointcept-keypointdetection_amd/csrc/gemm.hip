@@ -119,16 +119,21 @@ template <> struct Chunk16<__bf16> {
 // (Fetched one channel at a time inside the value loop - the first form of this epilogue - every element paid its
 // own s_waitcnt vmcnt(0): ~60 dependent round trips per wave, 2/3 of a short-K linear's run time.)
 struct EpiVec { f32x4 bias, scale, shift; };
-__device__ __forceinline__ EpiVec load_epi(const GemmArgs& a, int ch0) {
-  EpiVec e{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{1.f, 1.f, 1.f, 1.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  if (ch0 < a.cout) {
-    if (a.bias) e.bias = *reinterpret_cast<const f32x4*>(a.bias + ch0);
-    if (a.bn_scale) {
-      e.scale = *reinterpret_cast<const f32x4*>(a.bn_scale + ch0);
-      e.shift = *reinterpret_cast<const f32x4*>(a.bn_shift + ch0);
-    }
+// The tile's bn channels of the three vectors are parked in LDS at kernel start (sEpi: [3][bn] floats, visible after
+// the first barrier of the K loop): the epilogue reads them back with three ds_read_b128 per fragment - no registers
+// held across the K loop, no global load between the output stores.
+__device__ __forceinline__ void park_epi(const GemmArgs& a, float* sEpi, int bn, int n0, int tid, int nthreads) {
+  for (int t = tid; t < bn; t += nthreads) {
+    const int ch = n0 + t;
+    const bool in = ch < a.cout;
+    sEpi[t] = (in && a.bias) ? a.bias[ch] : 0.f;
+    sEpi[bn + t] = (in && a.bn_scale) ? a.bn_scale[ch] : 1.f;
+    sEpi[2 * bn + t] = (in && a.bn_scale) ? a.bn_shift[ch] : 0.f;
   }
-  return e;
+}
+__device__ __forceinline__ EpiVec load_epi(const float* sEpi, int bn, int cl) {
+  return EpiVec{*reinterpret_cast<const f32x4*>(sEpi + cl), *reinterpret_cast<const f32x4*>(sEpi + bn + cl),
+                *reinterpret_cast<const f32x4*>(sEpi + 2 * bn + cl)};
 }
 
 // phase 1 for one accumulator fragment: channels ch0..ch0+3 of tile row `rl` -> sOut[rl][cl..cl+3]
@@ -144,11 +149,11 @@ __device__ __forceinline__ void stage_values(const GemmArgs& a, T* sOut, int os,
 // phase 2: `rows` x `bn` tile in sOut (row stride os) -> out / out2, whole row segments, 16 bytes per lane.
 // Row lookups, residual loads and stores each go out in batches of UB: loads and stores share one in-order counter
 // (s_waitcnt vmcnt), so a lookup issued after a store would wait for that store to be acknowledged - per iteration.
-template <typename T>
+template <typename T, int UB>
 __device__ __forceinline__ void store_tile(const GemmArgs& a, const T* sOut, int os, int rows, int bn, int64_t row0,
                                            int n0, int tid, int nthreads) {
   constexpr int N = Chunk16<T>::N;
-  constexpr int UB = 8;
+  typedef typename Frag<T>::type FR;   // 16 bytes, kept packed until used (4 registers per chunk in flight)
   const int cpr = bn / N;
   const int total = rows * cpr;
   T* out = reinterpret_cast<T*>(a.out);
@@ -167,14 +172,14 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const T* sOut, int
       ok[u] = e < total && prow < a.m && col[u] < a.cout;
       orow[u] = ok[u] ? (a.row_order ? (int64_t)a.row_order[prow] : prow) : 0;
     }
-    float r[UB][N];
+    FR rraw[UB];
     if (res) {
       int64_t rrow[UB];
 #pragma unroll
       for (int u = 0; u < UB; ++u) rrow[u] = (ok[u] && a.res_index) ? (int64_t)a.res_index[orow[u]] : orow[u];
 #pragma unroll
       for (int u = 0; u < UB; ++u)
-        if (ok[u]) Chunk16<T>::load(res + rrow[u] * a.cout + col[u], r[u]);
+        if (ok[u]) rraw[u] = *reinterpret_cast<const FR*>(res + rrow[u] * a.cout + col[u]);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
@@ -183,8 +188,10 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const T* sOut, int
       Chunk16<T>::load(sOut + (size_t)rl[u] * os + (col[u] - n0), v);
       if (res) {
         if (out2) Chunk16<T>::store(out + orow[u] * a.cout + col[u], v);
+        float r[N];
+        Chunk16<T>::load(reinterpret_cast<const T*>(&rraw[u]), r);
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] += r[u][i];
+        for (int i = 0; i < N; ++i) v[i] += r[i];
         Chunk16<T>::store((out2 ? out2 : out) + orow[u] * a.cout + col[u], v);
       } else {
         Chunk16<T>::store(out + orow[u] * a.cout + col[u], v);
@@ -195,7 +202,10 @@ __device__ __forceinline__ void store_tile(const GemmArgs& a, const T* sOut, int
 
 // GATHER: rows of x come through the neighbour table (sparse convolution); a separate instantiation, so the dense
 // linear carries none of the index arithmetic and the two show up under their own names in rocprofv3 / PMC tables
-template <typename T, int NT, bool GATHER>
+// PD: K steps fetched ahead into a register ring.  1 for chip-filling grids (occupancy hides the latency); 4 for the
+// small grids of the deep levels, where a workgroup is alone on its CU and every K step otherwise costs a full
+// global round trip (K = 256: all four stages are in flight before the first one is needed).
+template <typename T, int NT, bool GATHER, int PD = 1>
 __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   constexpr int BN = 16 * NT;  // output channels per workgroup
   typedef Frag<T> F;
@@ -211,6 +221,7 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) T smem_all[SM_OPER > SM_OUT ? SM_OPER : SM_OUT];
   T* sA = smem_all;
   T* sB = smem_all + GM_BM * LS;
+  __shared__ __attribute__((aligned(16))) float sEpi[3 * BN];
 
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
@@ -245,8 +256,9 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
     b_ch[u] = e % CPR;
   }
 
-  FR ra[A_LOADS], rb[B_LOADS];
-  auto issue = [&](int step) {
+  if (!a.slab) park_epi(a, sEpi, BN, n0, tid, GM_THREADS);
+  FR rra[PD][A_LOADS], rrb[PD][B_LOADS];
+  auto issue = [&](int step, FR (&ra)[A_LOADS], FR (&rb)[B_LOADS]) {
     const int k0 = step * BK;
 #pragma unroll
     for (int u = 0; u < A_LOADS; ++u) {
@@ -271,7 +283,7 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
       if (o < a.cout && kk < ktot) rb[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](const FR (&ra)[A_LOADS], const FR (&rb)[B_LOADS]) {
 #pragma unroll
     for (int u = 0; u < A_LOADS; ++u) *reinterpret_cast<FR*>(sA + a_r[u] * LS + E * a_ch[u]) = ra[u];
 #pragma unroll
@@ -282,33 +294,39 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (step_lo < step_hi) issue(step_lo);
-  for (int step = step_lo; step < step_hi; ++step) {
-    stash();
-    __syncthreads();
-    if (step + 1 < step_hi) issue(step + 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      FR xf = *reinterpret_cast<const FR*>(sA + (16 * wave + li) * LS + F::KC * ks + E * g);
+  for (int p = 0; p < PD; ++p)
+    if (step_lo + p < step_hi) issue(step_lo + p, rra[p], rrb[p]);
+  for (int base = step_lo; base < step_hi; base += PD) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        FR wf = *reinterpret_cast<const FR*>(sB + (16 * j + li) * LS + F::KC * ks + E * g);
-        acc[j] = F::mma(wf, xf, acc[j]);  // D[channel 4g+r][point li]
+    for (int p = 0; p < PD; ++p) {
+      const int step = base + p;
+      if (step >= step_hi) break;   // workgroup-uniform
+      stash(rra[p], rrb[p]);
+      __syncthreads();
+      if (step + PD < step_hi) issue(step + PD, rra[p], rrb[p]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        FR xf = *reinterpret_cast<const FR*>(sA + (16 * wave + li) * LS + F::KC * ks + E * g);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          FR wf = *reinterpret_cast<const FR*>(sB + (16 * j + li) * LS + F::KC * ks + E * g);
+          acc[j] = F::mma(wf, xf, acc[j]);  // D[channel 4g+r][point li]
+        }
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- epilogue: lane owns point (16*wave + li), channels n0 + 16j + 4g .. +3
   if (!a.slab && (a.cout % Chunk16<T>::N) == 0) {
     // whole rows of the tile through LDS (the operand tiles are dead: the K loop ended on a barrier)
-    EpiVec ev[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) ev[j] = load_epi(a, n0 + 16 * j + 4 * g);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) stage_values<T>(a, smem_all, OS, 16 * wave + li, 16 * j + 4 * g, ev[j], acc[j]);
+    for (int j = 0; j < NT; ++j)
+      stage_values<T>(a, smem_all, OS, 16 * wave + li, 16 * j + 4 * g, load_epi(sEpi, BN, 16 * j + 4 * g), acc[j]);
     __syncthreads();
-    store_tile<T>(a, smem_all, OS, GM_BM, BN, row0, n0, tid, GM_THREADS);
+    store_tile<T, (GM_BM * BN / Chunk16<T>::N + GM_THREADS - 1) / GM_THREADS>(a, smem_all, OS, GM_BM, BN, row0, n0, tid,
+                                                                              GM_THREADS);
     return;
   }
   const int64_t prow = row0 + 16 * wave + li;
@@ -349,6 +367,7 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
 constexpr int GB_BM = 128;
 constexpr int GB_THREADS = 256;
 constexpr int GB_MAX_KVOL = 27;
+constexpr int GB_MAX_STEPS = 256;   // K steps a tile can list for tap skipping (27 taps x 512 channels / 64 = 216)
 
 template <typename T, int WM, int WN, int BN, bool GATHER>
 __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
@@ -365,6 +384,12 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   T* sX = reinterpret_cast<T*>(gb_smem);                         // [2][128][BK]
   T* sW = sX + 2 * GB_BM * BK;                                   // [2][BN][BK]
   int32_t* sNbr = reinterpret_cast<int32_t*>(sW + 2 * BN * BK);  // [128][kvol]
+  // GATHER: the K steps that touch at least one active tap of this tile.  One byte each: with the 64 KB of operand
+  // buffers, the 13.5 KB neighbour table and the epilogue vectors a workgroup must stay under 80 KB (two per CU)
+  __shared__ unsigned char sSteps[GB_MAX_STEPS];
+  __shared__ unsigned sTapMask;
+  __shared__ int sWaveCnt[4];
+  __shared__ __attribute__((aligned(16))) float sEpi[3 * BN];
 
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
@@ -391,20 +416,51 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
     const int64_t r = row0 + r0 + 32 * u;
     xrow[u] = r < a.m ? (a.row_order ? (int64_t)a.row_order[r] : r) : -1;
   }
+  int nact = nsteps;   // K steps this tile really runs
   if constexpr (GATHER) {
-    // neighbour rows of the tile's points -> LDS (row-major [point][kvol])
+    // neighbour rows of the tile's points -> LDS (row-major [point][kvol]), and which taps any of them has
+    if (tid == 0) sTapMask = 0u;
+    __syncthreads();
+    unsigned mask = 0u;
     for (int e = tid; e < GB_BM * a.kvol; e += GB_THREADS) {
       const int pr = e / a.kvol, d = e - pr * a.kvol;
       const int64_t r = row0 + pr;
       int32_t v = -1;
       if (r < a.m) v = a.nbr[(a.row_order ? (int64_t)a.row_order[r] : r) * a.kvol + d];
       sNbr[e] = v;
+      if (v >= 0) mask |= 1u << d;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, 64);
+    if (lane == 0 && mask) atomicOr(&sTapMask, mask);
     __syncthreads();
+    // Points that are neighbours in space (rows come in z-order) miss the same taps: a K step whose taps are empty
+    // for the WHOLE tile contributes exact zeros and is skipped - its loads and its matrix-core work (a thin surface
+    // or a LiDAR sheet leaves 50-75 % of the 27 taps empty).  The list keeps K order: results are bitwise unchanged.
+    if (nsteps <= GB_MAX_STEPS) {
+      const unsigned tm = sTapMask;
+      bool act = false;
+      if (tid < nsteps) {
+        const int d0 = (tid * BK) / a.cin, d1 = min(a.kvol - 1, (tid * BK + BK - 1) / a.cin);
+        for (int d = d0; d <= d1; ++d) act |= (tm >> d) & 1u;
+      }
+      const unsigned long long bal = __ballot(act);
+      if (lane == 0) sWaveCnt[wave] = __popcll(bal);
+      __syncthreads();
+      int base = 0;
+      for (int wv = 0; wv < wave; ++wv) base += sWaveCnt[wv];
+      if (act) sSteps[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned char)tid;
+      nact = sWaveCnt[0] + sWaveCnt[1] + sWaveCnt[2] + sWaveCnt[3];
+      __syncthreads();
+    }
   }
+  auto step_of = [&](int i) { return (GATHER && nsteps <= GB_MAX_STEPS) ? (int)sSteps[i] : i; };
 
-  FR rx[X_LOADS], rw[W_LOADS];
-  auto issue = [&](int step) {
+  park_epi(a, sEpi, BN, n0, tid, GB_THREADS);
+  // two register sets: while tile t is in the matrix core, tile t+1 sits in one set (written to LDS at the top of the
+  // next step) and tile t+2 is on its way into the other - one K step of compute does not cover an L2 round trip
+  FR rxa[X_LOADS], rwa[W_LOADS], rxb[X_LOADS], rwb[W_LOADS];
+  auto issue = [&](int step, FR (&rx)[X_LOADS], FR (&rw)[W_LOADS]) {
     const int kk = step * BK + E * c;
     const bool kin = kk < ktot;
     int d = 0, cc = kk;
@@ -426,7 +482,7 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
       if (kin && o < a.cout && !(a.debug & 2)) rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
     }
   };
-  auto stash = [&](int buf) {
+  auto stash = [&](int buf, const FR (&rx)[X_LOADS], const FR (&rw)[W_LOADS]) {
 #pragma unroll
     for (int u = 0; u < X_LOADS; ++u) {
       const int r = r0 + 32 * u;
@@ -445,14 +501,24 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  issue(0);
-  stash(0);
-  if (nsteps > 1) issue(1);
+  if (nact > 0) {
+    issue(step_of(0), rxa, rwa);
+    stash(0, rxa, rwa);
+  }
+  if (nact > 1) issue(step_of(1), rxa, rwa);
+  if (nact > 2) issue(step_of(2), rxb, rwb);
   __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
+  for (int step = 0; step < nact; ++step) {
     const int buf = step & 1;
-    if (step + 1 < nsteps) stash(buf ^ 1);      // tile step+1: its readers (step-1) are behind the last barrier
-    if (step + 2 < nsteps) issue(step + 2);
+    // tile step+1 goes to the idle buffer (its readers, step-1, are behind the last barrier); its register set then
+    // takes tile step+3
+    if (buf == 0) {
+      if (step + 1 < nact) stash(1, rxa, rwa);
+      if (step + 3 < nact) issue(step_of(step + 3), rxa, rwa);
+    } else {
+      if (step + 1 < nact) stash(0, rxb, rwb);
+      if (step + 3 < nact) issue(step_of(step + 3), rxb, rwb);
+    }
     const T* bx = sX + (size_t)buf * GB_BM * BK;
     const T* bw = sW + (size_t)buf * BN * BK;
 #pragma unroll
@@ -482,16 +548,15 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   if ((a.cout % Chunk16<T>::N) == 0) {
     constexpr int OS = BN + 16 / (int)sizeof(T);
     T* sOut = reinterpret_cast<T*>(gb_smem);   // 128 x (BN + pad) T <= the operand buffers
-    EpiVec ev[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) ev[j] = load_epi(a, n0 + (NJ * wc + j) * 16 + 4 * g);
+    for (int j = 0; j < NJ; ++j) {
+      const EpiVec ev = load_epi(sEpi, BN, (NJ * wc + j) * 16 + 4 * g);
 #pragma unroll
-    for (int m = 0; m < MI; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        stage_values<T>(a, sOut, OS, (MI * wr + m) * 16 + li, (NJ * wc + j) * 16 + 4 * g, ev[j], acc[m][j]);
+      for (int m = 0; m < MI; ++m)
+        stage_values<T>(a, sOut, OS, (MI * wr + m) * 16 + li, (NJ * wc + j) * 16 + 4 * g, ev, acc[m][j]);
+    }
     __syncthreads();
-    store_tile<T>(a, sOut, OS, GB_BM, BN, row0, n0, tid, GB_THREADS);
+    store_tile<T, 8>(a, sOut, OS, GB_BM, BN, row0, n0, tid, GB_THREADS);
     return;
   }
 #pragma unroll
@@ -513,7 +578,9 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
 static bool use_big_tile(int64_t m, int cin, int cout, int kvol, int dtype, int* bn_out) {
   const char* env = getenv("PTV3_GEMM_BIG");  // 0 off, 1 policy (default), 2 force; read per call so tests can switch
   const int mode = env ? atoi(env) : 1;
-  if (mode == 0 || kvol > GB_MAX_KVOL || cout < 64) return false;
+  // 128-channel variant only: at 64 output channels the 64-point tile measured faster (dec-0 conv 85 vs 100 us,
+  // 120k x 64 x 64 linear 11.5 vs 13.2 us) - its grid is four times larger and W is tiny
+  if (mode == 0 || kvol > GB_MAX_KVOL || cout < (mode == 2 ? 64 : 128)) return false;
   const int bn = cout >= 128 ? 128 : 64;
   *bn_out = bn;
   const int64_t tiles = cdiv(m, GB_BM) * cdiv(cout, bn);
@@ -640,6 +707,8 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   if (big) {
     const size_t lds_out = (size_t)GB_BM * (big_bn * esz + 16);   // staged output tile of the coalesced epilogue
     const size_t lds = std::max((size_t)2 * (GB_BM + big_bn) * 128 + (nbr ? (size_t)GB_BM * kvol * 4 : 0), lds_out);
+    static_assert(2 * (GB_BM + 128) * 128 + GB_BM * GB_MAX_KVOL * 4 + GB_MAX_STEPS + 32 + 3 * 128 * 4 <= 80 * 1024,
+                  "gemm_big_kernel: two workgroups per CU need <= 80 KB of LDS each");
     dim3 bgrid((unsigned)(cdiv(m, GB_BM) * cdiv(cout, big_bn)));
 #define GB_LAUNCH(T, WM_, WN_, BN_, G_)                                                                          \
     do {                                                                                                         \
@@ -673,15 +742,24 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
     case 12: hipLaunchKernelGGL((gemm_kernel<T, 12, G>), grid, dim3(GM_THREADS), 0, s, a); break;      \
     default: hipLaunchKernelGGL((gemm_kernel<T, 16, G>), grid, dim3(GM_THREADS), 0, s, a); break;      \
   }
+  // small grids (the deep levels): four K stages in flight per workgroup instead of one
+  const char* pd_env = getenv("PTV3_GEMM_PD");
+  const bool deep = nt == 4 && (pd_env ? atoi(pd_env) == 4
+                                       : (int64_t)grid.x * grid.y * grid.z <= 1024);
   if (nbr) {
     // the gathered instantiations only exist for the tile widths the policy picks (2, 4)
     if (dtype == PTV3_F32) {
       if (nt == 2) hipLaunchKernelGGL((gemm_kernel<float, 2, true>), grid, dim3(GM_THREADS), 0, s, a);
+      else if (deep) hipLaunchKernelGGL((gemm_kernel<float, 4, true, 4>), grid, dim3(GM_THREADS), 0, s, a);
       else hipLaunchKernelGGL((gemm_kernel<float, 4, true>), grid, dim3(GM_THREADS), 0, s, a);
     } else {
       if (nt == 2) hipLaunchKernelGGL((gemm_kernel<__bf16, 2, true>), grid, dim3(GM_THREADS), 0, s, a);
+      else if (deep) hipLaunchKernelGGL((gemm_kernel<__bf16, 4, true, 4>), grid, dim3(GM_THREADS), 0, s, a);
       else hipLaunchKernelGGL((gemm_kernel<__bf16, 4, true>), grid, dim3(GM_THREADS), 0, s, a);
     }
+  } else if (deep) {
+    if (dtype == PTV3_F32) hipLaunchKernelGGL((gemm_kernel<float, 4, false, 4>), grid, dim3(GM_THREADS), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<__bf16, 4, false, 4>), grid, dim3(GM_THREADS), 0, s, a);
   } else if (dtype == PTV3_F32) { GM_LAUNCH(float, false) } else { GM_LAUNCH(__bf16, false) }
 #undef GM_LAUNCH
   prof_end(prof, s);   // the bracket times the GEMM launch alone (the slab reduce below is its own, tiny kernel)

@@ -62,11 +62,13 @@ window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_or
   // ---- Q fragments (B operand of the score product), pre-scaled by scale*log2(e)
   V4 qf[QT][ND];
   int qidx[QT];
+  bool keep[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
     qidx[t] = qs * QB + (wave * QT + t) * 16 + li;
     const bool qv = qidx[t] < K;
     const int row = qv ? sOrd[qidx[t]] : 0;
+    keep[t] = qv && win_inverse[row] == (int32_t)(wbase + qidx[t]);
 #pragma unroll
     for (int c = 0; c < ND; ++c) {
       V4 raw = zero4<T>();
@@ -204,14 +206,12 @@ window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_or
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
     const float inv = 1.0f / lt;
-    if (qidx[t] < K) {
+    if (keep[t]) {
       const int row = sOrd[qidx[t]];
-      if (win_inverse[row] == (int32_t)(wbase + qidx[t])) {
 #pragma unroll
-        for (int c = 0; c < ND; ++c) {
-          V4 v = pack4<T>(o[t][c][0] * inv, o[t][c][1] * inv, o[t][c][2] * inv, o[t][c][3] * inv);
-          *reinterpret_cast<V4*>(out + (int64_t)row * C + h * D + 16 * c + 4 * g) = v;
-        }
+      for (int c = 0; c < ND; ++c) {
+        V4 v = pack4<T>(o[t][c][0] * inv, o[t][c][1] * inv, o[t][c][2] * inv, o[t][c][3] * inv);
+        *reinterpret_cast<V4*>(out + (int64_t)row * C + h * D + 16 * c + 4 * g) = v;
       }
     }
   }
@@ -358,6 +358,8 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   V4 qf[QT][ND];
   int qidx[QT];
   int qg[QT][3];
+  bool keep[QT];   // this slot is the point's own (not a borrowed duplicate): fetched NOW - a load issued between the
+                   // stores of the epilogue would wait for every earlier store to be acknowledged (one in-order counter)
   bool any_q = false;
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -365,6 +367,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
     const bool qv = qidx[t] < K;
     any_q |= qv;
     const int row = qv ? sOrd[qidx[t]] : 0;
+    keep[t] = qv && win_inverse[row] == (int32_t)(wbase + qidx[t]);
     if constexpr (RPE == 2) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) qg[t][d] = qv ? rt.grid[(int64_t)row * 3 + d] : 0;
@@ -507,14 +510,12 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   for (int t = 0; t < QT; ++t) {
     const float lsum = SUM_MFMA ? lacc[t][0] : lanes_sum_groups(lacc[t][0]);
     const float inv = 1.0f / lsum;
-    if (qidx[t] < K) {
+    if (keep[t]) {
       const int row = sOrd[qidx[t]];
-      if (win_inverse[row] == (int32_t)(wbase + qidx[t])) {
 #pragma unroll
-        for (int c = 0; c < ND; ++c) {
-          V4 v = pack4<T>(o[t][c][0] * inv, o[t][c][1] * inv, o[t][c][2] * inv, o[t][c][3] * inv);
-          *reinterpret_cast<V4*>(out + (int64_t)row * C + h * D + 16 * c + 4 * g) = v;
-        }
+      for (int c = 0; c < ND; ++c) {
+        V4 v = pack4<T>(o[t][c][0] * inv, o[t][c][1] * inv, o[t][c][2] * inv, o[t][c][3] * inv);
+        *reinterpret_cast<V4*>(out + (int64_t)row * C + h * D + 16 * c + 4 * g) = v;
       }
     }
   }

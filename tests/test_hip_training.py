@@ -312,3 +312,100 @@ def test_train_step_with_rpe_vs_oracle_autograd(dev):
     worst = max(((n, _rel(p.grad, ref_grads[n], 1e-3 * gmax)) for n, p in model.named_parameters()),
                 key=lambda t: t[1])
     assert worst[1] < 2e-3, worst
+
+
+def test_eval_between_fused_adamw_steps_sees_new_weights(dev):
+    """train -> eval -> train -> eval with FusedAdamW (the evaluator-hook flow of tools/train.py): the step kernel
+    writes the parameters through raw pointers, so it must bump their torch version - every eval-side cache (cast /
+    permuted / folded weights, the native executor's packed table) is keyed on it.  The second evaluation has to equal
+    a freshly built model loaded from the same state_dict, on the executor and on the module path."""
+    import ptv3_scenes as S
+    from ptv3_hip.optim import FusedAdamW
+    cfg = dict(TINY_CFG, drop_path=0.0)
+    torch.manual_seed(31)
+    model = _build(cfg, hidden_dim=32).to(dev)
+    opt = FusedAdamW(model.parameters(), lr=5e-3, weight_decay=0.01)
+    data = {k: v.to(dev) for k, v in S.make_batch([1200, 800], in_channels=4, extent=64, seed=8, with_target=6).items()}
+
+    def evaluate(m, use_engine):
+        m.eval()
+        m.backbone.use_engine = use_engine
+        torch.manual_seed(3)
+        with torch.no_grad():
+            return m(data)["pred"].clone()
+
+    def train_steps(n):
+        model.train()
+        for _ in range(n):
+            opt.zero_grad()
+            torch.manual_seed(4)
+            model(data)["loss"].backward()
+            opt.step()
+
+    first = {u: evaluate(model, u) for u in (True, False)}          # fills every eval cache
+    versions = [p._version for p in model.parameters()]
+    train_steps(3)
+    assert all(p._version > v for p, v in zip(model.parameters(), versions))
+    for use in (True, False):
+        got = evaluate(model, use)
+        fresh = _build(cfg, hidden_dim=32)
+        fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=True)
+        want = evaluate(fresh.to(dev), use)
+        assert torch.equal(got, want), use
+        assert not torch.equal(got, first[use])
+    train_steps(2)                                                   # and once more round the loop
+    fresh = _build(cfg, hidden_dim=32)
+    fresh.load_state_dict({k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, strict=True)
+    assert torch.equal(evaluate(model, True), evaluate(fresh.to(dev), True))
+
+
+def test_fused_adamw_state_dict_round_trip_with_torch_adamw(dev):
+    """Checkpoints are interchangeable with torch.optim.AdamW (engines/hooks/misc.py:269 resumes with
+    optimizer.load_state_dict): per-parameter state["step"] survives save / load in both directions and the bias
+    corrections continue from it."""
+    from ptv3_hip.optim import FusedAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 32), (32,), (16, 27, 8), (8,)]
+
+    def params():
+        gg = torch.Generator().manual_seed(1)
+        return [torch.nn.Parameter(torch.randn(s, generator=gg).to(dev)) for s in shapes]
+
+    grads = [[torch.randn(s, generator=g).to(dev) for s in shapes] for _ in range(6)]
+
+    def run(opt, ps, steps):
+        for k in steps:
+            for p, gr in zip(ps, grads[k]):
+                p.grad = gr.clone()
+            opt.step()
+
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.1)
+    # reference: torch AdamW for 6 steps
+    pt = params(); ot = torch.optim.AdamW(pt, **kw); run(ot, pt, range(6))
+    # fused for 3 steps -> state_dict -> torch AdamW continues
+    pf = params(); of = FusedAdamW(pf, **kw); run(of, pf, range(3))
+    sd = of.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    p2 = [torch.nn.Parameter(p.detach().clone()) for p in pf]; o2 = torch.optim.AdamW(p2, **kw)
+    o2.load_state_dict(sd); run(o2, p2, range(3, 6))
+    for a, b in zip(p2, pt):
+        assert (a - b).abs().max().item() < 2e-6
+    # torch AdamW for 3 steps -> state_dict -> fused continues (resume path)
+    p3 = params(); o3 = torch.optim.AdamW(p3, **kw); run(o3, p3, range(3))
+    p4 = [torch.nn.Parameter(p.detach().clone()) for p in p3]; o4 = FusedAdamW(p4, **kw)
+    o4.load_state_dict(o3.state_dict()); run(o4, p4, range(3, 6))
+    for a, b in zip(p4, pt):
+        assert (a - b).abs().max().item() < 2e-6
+    assert all(float(st["step"]) == 6.0 for st in o4.state_dict()["state"].values())
+    # a parameter that joins late keeps its own count (per-entry lag inside the one launch)
+    p5 = params(); o5 = FusedAdamW(p5, **kw)
+    p6 = params(); o6 = torch.optim.AdamW(p6, **kw)
+    for k in range(4):
+        for i, (a, b) in enumerate(zip(p5, p6)):
+            a.grad = b.grad = None
+            if k >= 2 or i != 1:                 # parameter 1 gets no gradient in the first two steps
+                a.grad, b.grad = grads[k][i].clone(), grads[k][i].clone()
+        o5.step(); o6.step()
+    for a, b in zip(p5, p6):
+        assert (a - b).abs().max().item() < 2e-6
+    assert [float(st["step"]) for st in o5.state_dict()["state"].values()] == [4.0, 2.0, 4.0, 4.0]

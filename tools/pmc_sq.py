@@ -10,7 +10,10 @@ the CUs that held waves of this kernel during which the matrix pipe was executin
 import collections
 import csv
 import json
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import label  # noqa: E402
 
 
 def main():
@@ -25,9 +28,7 @@ def main():
         if d < lo:
             continue
         n = r["Kernel_Name"]
-        key = ("gemm_kernel<bf16,64ch>" if "gemm_kernel" in n and "Li4E" in n else
-               "gemm_kernel<bf16,32ch>" if "gemm_kernel" in n else
-               n.split("(")[0].replace("void ", "").replace("ptv3::", "").split("<")[0][-44:])
+        key = label(n)
         agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[key].add(d)
     res = {}

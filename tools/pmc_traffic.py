@@ -2,11 +2,14 @@
 
 usage: python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <forwards> <out.json> [workload json]
 Units / corrections exactly as /opt/skills/guides/MI355X_MICROARCH.md section HBM prescribes:
-  FETCH_SIZE, WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane)
-  coalesced reads -> doubled here (every load of these kernels is a 16-byte-per-lane access); WRITE_SIZE is exact
-  for 16-B-per-lane streaming stores (the epilogues store 8 or 16 B per lane: uncalibrated for the 8-B case, taken as is).
+  FETCH_SIZE, WRITE_SIZE are in KiB (x1024); on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide (>= 128 B per row)
+  coalesced reads -> doubled for the kernels whose reads are such streams (dense GEMM operands, block halves,
+  LayerNorm ...).  The gathered launches (sparse-conv instantiations, window attention, neighbour search) read 32-128
+  byte row pieces: their FETCH_SIZE is reported BOTH ways (x1 = `fetch_bytes_per_step_raw`, x2 =
+  `fetch_bytes_per_step`), the truth lies between.  WRITE_SIZE is taken as is.
 """
-import collections, csv, json, sys
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def per_kernel(path, counter, nf):
@@ -25,14 +28,7 @@ def per_kernel(path, counter, nf):
     return {k: (v / nf, len(cnt[k]) / nf) for k, v in tot.items()}
 
 
-def short(name):
-    if "gemm_kernel" in name:
-        return "gemm_kernel<bf16,%s>" % ("64ch" if "Li4E" in name else "32ch") if "DF16b" in name else "gemm_kernel<f32>"
-    for k in ("window_attn_full_kernel", "window_attn_kernel", "splitk_reduce_kernel", "layernorm_kernel",
-              "ht_neighbors_kernel", "pool_feat_kernel"):
-        if k in name:
-            return k
-    return name.split("(")[0][:40]
+from kernel_names import label as short, is_gather  # noqa: E402
 
 
 def main():
@@ -44,6 +40,8 @@ def main():
     for name, (v, n) in f.items():
         a = agg[short(name)]
         a["fetch_bytes_per_step"] += v * 1024 * 2   # KiB -> B, gfx950 half-count correction
+        if is_gather(short(name)):
+            a["fetch_bytes_per_step_raw"] = a.get("fetch_bytes_per_step_raw", 0.0) + v * 1024
         a["launches_per_step"] += n
     for name, (v, n) in w.items():
         agg[short(name)]["write_bytes_per_step"] += v * 1024

@@ -1,6 +1,8 @@
 """Summarise a rocprofv3 --kernel-trace CSV: per-kernel totals for the last `steps` forwards and GPU idle time.
 usage: python tools/summarize_trace.py <kernel_trace.csv> <num_forwards_in_trace>"""
-import csv, sys, collections
+import csv, sys, collections, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import label
 rows = list(csv.DictReader(open(sys.argv[1])))
 nf = int(sys.argv[2])
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -16,7 +18,7 @@ idle = 0.0
 for r in sel:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     name = r["Kernel_Name"]
-    short = name.split("(")[0].replace("void ", "").replace("ptv3::", "")[:60]
+    short = label(name)
     agg[short][0] += 1
     agg[short][1] += (e - s) / 1e3
     if s > last_end:
