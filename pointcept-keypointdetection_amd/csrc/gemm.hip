@@ -25,7 +25,6 @@ struct GemmArgs {
   const float* bias; const float* bn_scale; const float* bn_shift;
   float* slab;  // split-K partial sums [splits][m][cout] fp32 (NULL: direct epilogue)
   int64_t m; int cin; int cout; int kvol; int act; int cin_shift; int steps_per_split;
-  int debug;  // experiments only (PTV3_GEMM_DEBUG): 1 skip stores, 2 skip global loads, 4 skip the matrix core
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -222,6 +221,9 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   T* sA = smem_all;
   T* sB = smem_all + GM_BM * LS;
   __shared__ __attribute__((aligned(16))) float sEpi[3 * BN];
+  // GATHER, kvol <= 27: the neighbour rows of the tile's 64 points, so that a stage's row addresses need no dependent
+  // global read (the 5^3 stem conv keeps reading the table from memory)
+  __shared__ int32_t sNbr[GATHER ? GM_BM * 27 : 1];
 
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ w = reinterpret_cast<const T*>(a.w);
@@ -257,37 +259,62 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
   }
 
   if (!a.slab) park_epi(a, sEpi, BN, n0, tid, GM_THREADS);
+  const bool nbr_lds = GATHER && a.kvol <= 27;
+  if constexpr (GATHER) {
+    if (nbr_lds) {
+      for (int e = tid; e < GM_BM * a.kvol; e += GM_THREADS) {
+        const int pr = e / a.kvol, d = e - pr * a.kvol;
+        const int64_t r = row0 + pr;
+        sNbr[e] = r < a.m ? a.nbr[(a.row_order ? (int64_t)a.row_order[r] : r) * a.kvol + d] : -1;
+      }
+      __syncthreads();
+    }
+  }
+  // The operand loads of a stage are issued unconditionally (rows / channels / K past the end and missing neighbours
+  // read a valid dummy address and are zeroed when the stage goes to LDS): a load inside a branch makes the compiler
+  // wait with s_waitcnt vmcnt(0) in front of the LDS write - for every younger stage of the ring too.  The sparse-conv
+  // neighbour index is the one dependent read; it is fetched with the stage and costs its own (L2-hit) round trip.
   FR rra[PD][A_LOADS], rrb[PD][B_LOADS];
-  auto issue = [&](int step, FR (&ra)[A_LOADS], FR (&rb)[B_LOADS]) {
+  unsigned rok[PD];
+  auto issue = [&](int step, FR (&ra)[A_LOADS], FR (&rb)[B_LOADS], unsigned& ok) {
     const int k0 = step * BK;
+    ok = 0;
+    int64_t src[A_LOADS];
+    int cc[A_LOADS];
 #pragma unroll
     for (int u = 0; u < A_LOADS; ++u) {
-      ra[u] = F::zero();
-      int kk = k0 + E * a_ch[u];
-      if (arow[u] >= 0 && kk < ktot) {
-        int64_t src = arow[u];
-        int c = kk;
-        if constexpr (GATHER) {
-          int d = a.cin_shift >= 0 ? (kk >> a.cin_shift) : (kk / a.cin);
-          c = kk - d * a.cin;
-          src = a.nbr[arow[u] * a.kvol + d];
-        }
-        if (src >= 0) ra[u] = *reinterpret_cast<const FR*>(x + src * a.cin + c);
+      const int kk = k0 + E * a_ch[u];
+      const bool in = arow[u] >= 0 && kk < ktot;
+      const int kks = in ? kk : 0;
+      src[u] = in ? arow[u] : 0;
+      cc[u] = kks;
+      if constexpr (GATHER) {
+        const int d = a.cin_shift >= 0 ? (kks >> a.cin_shift) : (kks / a.cin);
+        cc[u] = kks - d * a.cin;
+        src[u] = nbr_lds ? (int64_t)sNbr[a_r[u] * a.kvol + d] : (int64_t)a.nbr[src[u] * a.kvol + d];
       }
+      const bool v = in && src[u] >= 0;
+      ok |= (unsigned)v << u;
+      if (!v) src[u] = 0;
     }
+#pragma unroll
+    for (int u = 0; u < A_LOADS; ++u) ra[u] = *reinterpret_cast<const FR*>(x + src[u] * a.cin + cc[u]);
 #pragma unroll
     for (int u = 0; u < B_LOADS; ++u) {
-      rb[u] = F::zero();
-      int kk = k0 + E * b_ch[u];
-      int o = n0 + b_r[u];
-      if (o < a.cout && kk < ktot) rb[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
+      const int kk = k0 + E * b_ch[u];
+      const int o = n0 + b_r[u];
+      const bool v = o < a.cout && kk < ktot;
+      ok |= (unsigned)v << (8 + u);
+      rb[u] = *reinterpret_cast<const FR*>(w + (int64_t)(v ? o : 0) * ktot + (v ? kk : 0));
     }
   };
-  auto stash = [&](const FR (&ra)[A_LOADS], const FR (&rb)[B_LOADS]) {
+  auto stash = [&](const FR (&ra)[A_LOADS], const FR (&rb)[B_LOADS], unsigned ok) {
 #pragma unroll
-    for (int u = 0; u < A_LOADS; ++u) *reinterpret_cast<FR*>(sA + a_r[u] * LS + E * a_ch[u]) = ra[u];
+    for (int u = 0; u < A_LOADS; ++u)
+      *reinterpret_cast<FR*>(sA + a_r[u] * LS + E * a_ch[u]) = ((ok >> u) & 1u) ? ra[u] : F::zero();
 #pragma unroll
-    for (int u = 0; u < B_LOADS; ++u) *reinterpret_cast<FR*>(sB + b_r[u] * LS + E * b_ch[u]) = rb[u];
+    for (int u = 0; u < B_LOADS; ++u)
+      *reinterpret_cast<FR*>(sB + b_r[u] * LS + E * b_ch[u]) = ((ok >> (8 + u)) & 1u) ? rb[u] : F::zero();
   };
 
   f32x4 acc[NT];
@@ -296,15 +323,15 @@ __global__ void __launch_bounds__(GM_THREADS) gemm_kernel(GemmArgs a) {
 
 #pragma unroll
   for (int p = 0; p < PD; ++p)
-    if (step_lo + p < step_hi) issue(step_lo + p, rra[p], rrb[p]);
+    if (step_lo + p < step_hi) issue(step_lo + p, rra[p], rrb[p], rok[p]);
   for (int base = step_lo; base < step_hi; base += PD) {
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
       const int step = base + p;
       if (step >= step_hi) break;   // workgroup-uniform
-      stash(rra[p], rrb[p]);
+      stash(rra[p], rrb[p], rok[p]);
       __syncthreads();
-      if (step + PD < step_hi) issue(step + PD, rra[p], rrb[p]);
+      if (step + PD < step_hi) issue(step + PD, rra[p], rrb[p], rok[p]);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         FR xf = *reinterpret_cast<const FR*>(sA + (16 * wave + li) * LS + F::KC * ks + E * g);
@@ -457,41 +484,52 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   auto step_of = [&](int i) { return (GATHER && nsteps <= GB_MAX_STEPS) ? (int)sSteps[i] : i; };
 
   park_epi(a, sEpi, BN, n0, tid, GB_THREADS);
-  // two register sets: while tile t is in the matrix core, tile t+1 sits in one set (written to LDS at the top of the
-  // next step) and tile t+2 is on its way into the other - one K step of compute does not cover an L2 round trip
+  // ONE register set: tile t+1 is written to LDS at the top of step t, the set then takes tile t+2.  (A second set
+  // holding tile t+3 - two tiles in flight - measured slower on every shape, 208 VGPRs: 1.08x -> 1.17x of the
+  // 64-point tile on the 56k x 256 x 768 linear, 204 -> 239 us on the C = 256 sparse conv.)
+  // Every load of a stage is issued UNCONDITIONALLY (a missing neighbour, a row or channel past the end read a valid
+  // dummy address instead and are zeroed when the stage is written to LDS): loads inside branches make the compiler
+  // wait with s_waitcnt vmcnt(0) - for the younger stage too - where a counted wait leaves that stage in flight.
   FR rxa[X_LOADS], rwa[W_LOADS], rxb[X_LOADS], rwb[W_LOADS];
-  auto issue = [&](int step, FR (&rx)[X_LOADS], FR (&rw)[W_LOADS]) {
+  unsigned oka = 0, okb = 0;   // validity bits of the two stages: bit u = x chunk u, bit 8 + u = w chunk u
+  auto issue = [&](int step, FR (&rx)[X_LOADS], FR (&rw)[W_LOADS], unsigned& ok) {
     const int kk = step * BK + E * c;
     const bool kin = kk < ktot;
-    int d = 0, cc = kk;
+    const int kks = kin ? kk : 0;
+    int d = 0, cc = kks;
     if constexpr (GATHER) {
-      d = a.cin_shift >= 0 ? (kk >> a.cin_shift) : (kk / a.cin);
-      cc = kk - d * a.cin;
+      d = a.cin_shift >= 0 ? (kks >> a.cin_shift) : (kks / a.cin);
+      cc = kks - d * a.cin;
     }
+    ok = 0;
 #pragma unroll
     for (int u = 0; u < X_LOADS; ++u) {
-      rx[u] = F::zero();
       int64_t src = xrow[u];
-      if (GATHER && kin) src = sNbr[(r0 + 32 * u) * a.kvol + d];
-      if (kin && src >= 0 && !(a.debug & 2)) rx[u] = *reinterpret_cast<const FR*>(x + src * a.cin + cc);
+      if constexpr (GATHER) src = sNbr[(r0 + 32 * u) * a.kvol + d];
+      const bool v = kin && src >= 0;
+      ok |= (unsigned)v << u;
+      rx[u] = *reinterpret_cast<const FR*>(x + (v ? src : 0) * a.cin + cc);
     }
 #pragma unroll
     for (int u = 0; u < W_LOADS; ++u) {
-      rw[u] = F::zero();
       const int o = n0 + r0 + 32 * u;
-      if (kin && o < a.cout && !(a.debug & 2)) rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)o * ktot + kk);
+      const bool v = kin && o < a.cout;
+      ok |= (unsigned)v << (8 + u);
+      rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)(v ? o : 0) * ktot + kks);
     }
   };
-  auto stash = [&](int buf, const FR (&rx)[X_LOADS], const FR (&rw)[W_LOADS]) {
+  auto stash = [&](int buf, const FR (&rx)[X_LOADS], const FR (&rw)[W_LOADS], unsigned ok) {
 #pragma unroll
     for (int u = 0; u < X_LOADS; ++u) {
       const int r = r0 + 32 * u;
-      *reinterpret_cast<FR*>(sX + ((size_t)buf * GB_BM + r) * BK + E * (c ^ ((r >> 1) & 7))) = rx[u];
+      *reinterpret_cast<FR*>(sX + ((size_t)buf * GB_BM + r) * BK + E * (c ^ ((r >> 1) & 7))) =
+          ((ok >> u) & 1u) ? rx[u] : F::zero();
     }
 #pragma unroll
     for (int u = 0; u < W_LOADS; ++u) {
       const int r = r0 + 32 * u;
-      *reinterpret_cast<FR*>(sW + ((size_t)buf * BN + r) * BK + E * (c ^ ((r >> 1) & 7))) = rw[u];
+      *reinterpret_cast<FR*>(sW + ((size_t)buf * BN + r) * BK + E * (c ^ ((r >> 1) & 7))) =
+          ((ok >> (8 + u)) & 1u) ? rw[u] : F::zero();
     }
   };
 
@@ -501,24 +539,7 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (nact > 0) {
-    issue(step_of(0), rxa, rwa);
-    stash(0, rxa, rwa);
-  }
-  if (nact > 1) issue(step_of(1), rxa, rwa);
-  if (nact > 2) issue(step_of(2), rxb, rwb);
-  __syncthreads();
-  for (int step = 0; step < nact; ++step) {
-    const int buf = step & 1;
-    // tile step+1 goes to the idle buffer (its readers, step-1, are behind the last barrier); its register set then
-    // takes tile step+3
-    if (buf == 0) {
-      if (step + 1 < nact) stash(1, rxa, rwa);
-      if (step + 3 < nact) issue(step_of(step + 3), rxa, rwa);
-    } else {
-      if (step + 1 < nact) stash(0, rxb, rwb);
-      if (step + 3 < nact) issue(step_of(step + 3), rxb, rwb);
-    }
+  auto compute = [&](int buf) {
     const T* bx = sX + (size_t)buf * GB_BM * BK;
     const T* bw = sW + (size_t)buf * BN * BK;
 #pragma unroll
@@ -537,12 +558,44 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
 #pragma unroll
       for (int m = 0; m < MI; ++m)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          if (!(a.debug & 4)) acc[m][j] = F::mma(wf[j], xf[m], acc[m][j]);  // D[channel 4g+r][point li]
+        for (int j = 0; j < NJ; ++j) acc[m][j] = F::mma(wf[j], xf[m], acc[m][j]);  // D[channel 4g+r][point li]
     }
+  };
+  // Pipeline: LDS double buffer + two register sets.  Tile t+1 is written from its set into the idle LDS buffer at the
+  // top of step t (its readers, step t-1, are behind the last barrier); that set is then re-issued for tile t+3,
+  // while tile t+2 is still on its way into the other set: two tiles in flight per workgroup.  The steady state is
+  // branch-free (two steps per iteration, sets named statically) so that the wait in front of a write counts only the
+  // loads of ITS set (s_waitcnt vmcnt(n) with the younger set's loads left in flight), not vmcnt(0).
+  if (nact > 0) {
+    issue(step_of(0), rxa, rwa, oka);
+    stash(0, rxa, rwa, oka);
+  }
+  if (nact > 1) issue(step_of(1), rxa, rwa, oka);
+  if (nact > 2) issue(step_of(2), rxb, rwb, okb);
+  __syncthreads();
+  int step = 0;
+  for (; step + 4 < nact; step += 2) {
+    stash(1, rxa, rwa, oka);                  // tile step+1
+    issue(step_of(step + 3), rxa, rwa, oka);
+    compute(0);
+    __syncthreads();
+    stash(0, rxb, rwb, okb);                  // tile step+2
+    issue(step_of(step + 4), rxb, rwb, okb);
+    compute(1);
     __syncthreads();
   }
-  if (a.debug & 1) return;
+  for (; step < nact; ++step) {               // the last (up to four) steps, with the bounds checked
+    const int buf = step & 1;
+    if (buf == 0) {
+      if (step + 1 < nact) stash(1, rxa, rwa, oka);
+      if (step + 3 < nact) issue(step_of(step + 3), rxa, rwa, oka);
+    } else {
+      if (step + 1 < nact) stash(0, rxb, rwb, okb);
+      if (step + 3 < nact) issue(step_of(step + 3), rxb, rwb, okb);
+    }
+    compute(buf);
+    __syncthreads();
+  }
 
   // ---- epilogue: lane owns point (16 (MI wr + m) + li), channels n0 + 16 (NJ wc + j) + 4g .. +3
   if ((a.cout % Chunk16<T>::N) == 0) {
@@ -586,7 +639,11 @@ static bool use_big_tile(int64_t m, int cin, int cout, int kvol, int dtype, int*
   const int64_t tiles = cdiv(m, GB_BM) * cdiv(cout, bn);
   const int64_t ktot = (int64_t)kvol * cin;
   if (mode == 2) return true;
-  return tiles >= 256 && ktot >= 64 * (dtype == PTV3_F32 ? 1 : 2);
+  // long K only (sparse convs: K = 27 * cin; fc2 / wide linears: K >= 1024): there the deeper pipeline and the 64 x 64
+  // wave tile win (fc2 56k x 1024 x 256: 68 vs 81 us, 28k x 2048 x 512: 105 vs 139 us, C = 256 conv: 160 vs 260-340 us);
+  // at K = 256..512 a tile is four to eight steps, the fill / drain of the bigger tile costs more than it saves
+  // (qkv 56k x 256 x 768: 79 vs 69 us) and the 64-point tile keeps the job
+  return tiles >= 256 && ktot >= 1024;
 }
 
 // sums the split-K slabs in slab order and applies the epilogue: one thread per (row, 4 channels)
@@ -691,8 +748,7 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   int cin_shift = -1;
   if ((cin & (cin - 1)) == 0) { cin_shift = 0; while ((1 << cin_shift) < cin) ++cin_shift; }
   GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
-             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps, 0};
-  if (const char* dbg = getenv("PTV3_GEMM_DEBUG")) a.debug = atoi(dbg);
+             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps};
   hipStream_t s = (hipStream_t)stream;
   int nt = choose_nt(cout);
   if (nbr && nt != 2) nt = 4;
@@ -743,24 +799,34 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
     default: hipLaunchKernelGGL((gemm_kernel<T, 16, G>), grid, dim3(GM_THREADS), 0, s, a); break;      \
   }
   // small grids (the deep levels): four K stages in flight per workgroup instead of one
+  // register-ring depth: 4 for the small grids of the deep levels, PTV3_GEMM_PD_LARGE (default 1) for chip-filling ones
   const char* pd_env = getenv("PTV3_GEMM_PD");
-  const bool deep = nt == 4 && (pd_env ? atoi(pd_env) == 4
-                                       : (int64_t)grid.x * grid.y * grid.z <= 1024);
+  const char* pdl_env = getenv("PTV3_GEMM_PD_LARGE");
+  int pd = 1;
+  if (nt == 4) {
+    const bool small = (int64_t)grid.x * grid.y * grid.z <= 1024;
+    pd = pd_env ? atoi(pd_env) : (small ? 4 : (pdl_env ? atoi(pdl_env) : 1));
+    if (pd != 2 && pd != 4) pd = 1;
+  }
+#define GM_PD(T, G)                                                                                            \
+  do {                                                                                                         \
+    if (pd == 4) hipLaunchKernelGGL((gemm_kernel<T, 4, G, 4>), grid, dim3(GM_THREADS), 0, s, a);               \
+    else if (pd == 2) hipLaunchKernelGGL((gemm_kernel<T, 4, G, 2>), grid, dim3(GM_THREADS), 0, s, a);          \
+    else hipLaunchKernelGGL((gemm_kernel<T, 4, G, 1>), grid, dim3(GM_THREADS), 0, s, a);                       \
+  } while (0)
   if (nbr) {
     // the gathered instantiations only exist for the tile widths the policy picks (2, 4)
     if (dtype == PTV3_F32) {
       if (nt == 2) hipLaunchKernelGGL((gemm_kernel<float, 2, true>), grid, dim3(GM_THREADS), 0, s, a);
-      else if (deep) hipLaunchKernelGGL((gemm_kernel<float, 4, true, 4>), grid, dim3(GM_THREADS), 0, s, a);
-      else hipLaunchKernelGGL((gemm_kernel<float, 4, true>), grid, dim3(GM_THREADS), 0, s, a);
+      else GM_PD(float, true);
     } else {
       if (nt == 2) hipLaunchKernelGGL((gemm_kernel<__bf16, 2, true>), grid, dim3(GM_THREADS), 0, s, a);
-      else if (deep) hipLaunchKernelGGL((gemm_kernel<__bf16, 4, true, 4>), grid, dim3(GM_THREADS), 0, s, a);
-      else hipLaunchKernelGGL((gemm_kernel<__bf16, 4, true>), grid, dim3(GM_THREADS), 0, s, a);
+      else GM_PD(__bf16, true);
     }
-  } else if (deep) {
-    if (dtype == PTV3_F32) hipLaunchKernelGGL((gemm_kernel<float, 4, false, 4>), grid, dim3(GM_THREADS), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<__bf16, 4, false, 4>), grid, dim3(GM_THREADS), 0, s, a);
+  } else if (nt == 4) {
+    if (dtype == PTV3_F32) GM_PD(float, false); else GM_PD(__bf16, false);
   } else if (dtype == PTV3_F32) { GM_LAUNCH(float, false) } else { GM_LAUNCH(__bf16, false) }
+#undef GM_PD
 #undef GM_LAUNCH
   prof_end(prof, s);   // the bracket times the GEMM launch alone (the slab reduce below is its own, tiny kernel)
   if (splits > 1 && out != nullptr) {

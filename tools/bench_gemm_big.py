@@ -1,5 +1,5 @@
 """ptv3_gemm on the chip-filling shapes of BASELINE configs[2] (120k-point LiDAR scan): 64-point tile vs the large tile.
-usage: python tools/bench_gemm_big.py [debug masks...]   (PTV3_GEMM_DEBUG experiments: 1 no stores, 2 no loads, 4 no MFMA)"""
+usage: python tools/bench_gemm_big.py"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pointcept-keypointdetection_amd"))
