@@ -14,6 +14,8 @@ def label(name):
         pd = ",pd%s" % m.group(4) if m.group(4) and m.group(4) != "1" else ""
         return "gemm_kernel<%s,%dch%s> %s" % ("bf16" if m.group(1) == "DF16b" else "f32", 16 * int(m.group(2)), pd,
                                               "gather (sparse conv)" if m.group(3) == "1" else "dense")
+    if "gemm_kernel<bool _Accum" in n:   # rocprofv3's demangler on gemm_kernel<__bf16, 2, ...>: the 32-channel tile
+        return "gemm_kernel<bf16,32ch>"
     m = re.search(r"(block_head_coop|block_tail_coop|block_head|block_tail|mlp2|layernorm|splitk_reduce|pool_feat|"
                   r"gemm_tn|attn_bwd_dq|attn_bwd_dkv)_kernel", n)
     if m:

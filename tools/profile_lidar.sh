@@ -9,4 +9,4 @@ python bench.py $A --no-kernel-events > $O/lidar_bench_overlap.json 2>> $O/lidar
 rm -rf $O/lidar_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lidar_stats -- python bench.py $A --no-overlap --steps 5 --warmup 2 --no-kernel-events > $O/lidar_stats.log 2>&1
 python tools/summarize_trace.py "$(ls -t $O/lidar_stats/*/*_kernel_trace.csv | head -1)" 5 > $O/lidar_trace_summary.txt
-head -40 $O/lidar_trace_summary.txt
+head -12 $O/lidar_trace_summary.txt
