@@ -396,12 +396,8 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   }
   const V4 ones = RowSum<T>::ones();
 
-  // One 64-key tile against the wave's QT query tiles, in four phases over ALL query tiles - scores, row maxima,
-  // ONE wave vote for the (rare) rescale, then exp / P V - so that the QT independent chains sit in one basic block
-  // and the scheduler can interleave them (a vote + branch per query tile, the first form, fenced each chain off).
-  auto tile_body = [&](const int tile, auto mask_tag, auto first_tag) {
+  auto tile_body = [&](const int tile, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;
-    constexpr bool FIRST = decltype(first_tag)::value;   // the first tile pins the reference to its row maximum
     const int key0 = tile * WA_KT;
     V4 kf[4][ND], vf[ND][4];
 #pragma unroll
@@ -411,16 +407,15 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
         kf[kt][c] = *reinterpret_cast<const V4*>(sK + (size_t)(key0 + 16 * kt + li) * KS + 16 * c + 4 * g);
         vf[c][kt] = *reinterpret_cast<const V4*>(sV + (size_t)(16 * c + li) * VS + key0 + 16 * kt + 4 * g);
       }
-    f32x4 s[QT][4];  // score - reference max, log2 domain
-    float mx[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
+      f32x4 s[4];  // score - reference max, log2 domain
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
         f32x4 acc = negm[t];
 #pragma unroll
         for (int c = 0; c < ND; ++c) acc = mma16<T>(kf[kt][c], qf[t][c], acc);
-        s[t][kt] = acc;
+        s[kt] = acc;
       }
       if constexpr (RPE == 2) {
 #pragma unroll
@@ -434,7 +429,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
               const int rel = min(max(qg[t][d] - kg[d], -rt.pos_bnd), rt.pos_bnd) + rt.pos_bnd;
               bias += sTab[d * rpe_num + rel];
             }
-            s[t][kt][r] += bias;
+            s[kt][r] += bias;
           }
       }
       if constexpr (RPE == 1) {
@@ -445,7 +440,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               int key = key0 + 16 * kt + 4 * g + r;
-              if (key < K) s[t][kt][r] += rb[key] * 1.44269504088896340736f;
+              if (key < K) s[kt][r] += rb[key] * 1.44269504088896340736f;
             }
         }
       }
@@ -454,53 +449,40 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (key0 + 16 * kt + 4 * g + r >= K) s[t][kt][r] = -INFINITY;
+            if (key0 + 16 * kt + 4 * g + r >= K) s[kt][r] = -INFINITY;
       }
       // 16 values -> 8 x v_max3_f32
-      float m = max3_raw(s[t][0][0], s[t][0][1], s[t][0][2]);
-      m = max3_raw(m, s[t][0][3], s[t][1][0]);
-      m = max3_raw(m, s[t][1][1], s[t][1][2]);
-      m = max3_raw(m, s[t][1][3], s[t][2][0]);
-      m = max3_raw(m, s[t][2][1], s[t][2][2]);
-      m = max3_raw(m, s[t][2][3], s[t][3][0]);
-      m = max3_raw(m, s[t][3][1], s[t][3][2]);
-      mx[t] = fmaxf(m, s[t][3][3]);
-    }
-    // Lazy rescale (wave-uniform, per query tile): the first tile pins the reference to its row maximum; afterwards
-    // the exchange + rescale only run for a query tile some row maximum of which outgrew the reference by 2^THR.
-    bool grew = FIRST;
-    if constexpr (!FIRST) {
+      float mx = max3_raw(s[0][0], s[0][1], s[0][2]);
+      mx = max3_raw(mx, s[0][3], s[1][0]);
+      mx = max3_raw(mx, s[1][1], s[1][2]);
+      mx = max3_raw(mx, s[1][3], s[2][0]);
+      mx = max3_raw(mx, s[2][1], s[2][2]);
+      mx = max3_raw(mx, s[2][3], s[3][0]);
+      mx = max3_raw(mx, s[3][1], s[3][2]);
+      mx = fmaxf(mx, s[3][3]);
+      // Lazy rescale (wave-uniform): the first tile pins the reference to its row maximum; afterwards the
+      // exchange + rescale only run when some row maximum outgrew the reference by more than 2^THR.
+      if (__builtin_expect(tile == 0 || __any(mx > WA_RESCALE_THR), 0)) {
+        float d = lanes_max_groups(mx);      // new max - old reference (same for the 4 lanes of a query)
+        if (tile > 0) d = fmaxf(d, 0.f);     // the reference never moves down after the first tile
+        if (tile > 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+          lacc[t] *= alpha;
 #pragma unroll
-      for (int t = 0; t < QT; ++t) grew |= mx[t] > WA_RESCALE_THR;
-    }
-    if (__builtin_expect(FIRST || __any(grew), FIRST ? 1 : 0)) {
-#pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        if (FIRST || __any(mx[t] > WA_RESCALE_THR)) {
-          float d = lanes_max_groups(mx[t]);   // new max - old reference (same for the 4 lanes of a query)
-          if constexpr (!FIRST) {
-            d = fmaxf(d, 0.f);                 // the reference never moves down after the first tile
-            const float alpha = __builtin_amdgcn_exp2f(-d);
-            lacc[t] *= alpha;
-#pragma unroll
-            for (int c = 0; c < ND; ++c) o[t][c] *= alpha;
-          }
-          negm[t] -= d;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) s[t][kt] -= d;
+          for (int c = 0; c < ND; ++c) o[t][c] *= alpha;
         }
-      }
-    }
+        negm[t] -= d;
 #pragma unroll
-    for (int t = 0; t < QT; ++t) {
+        for (int kt = 0; kt < 4; ++kt) s[kt] -= d;
+      }
       float ps = 0.f;
       V4 pf[4];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) {
-        const float p0 = __builtin_amdgcn_exp2f(s[t][kt][0]);
-        const float p1 = __builtin_amdgcn_exp2f(s[t][kt][1]);
-        const float p2 = __builtin_amdgcn_exp2f(s[t][kt][2]);
-        const float p3 = __builtin_amdgcn_exp2f(s[t][kt][3]);
+        const float p0 = __builtin_amdgcn_exp2f(s[kt][0]);
+        const float p1 = __builtin_amdgcn_exp2f(s[kt][1]);
+        const float p2 = __builtin_amdgcn_exp2f(s[kt][2]);
+        const float p3 = __builtin_amdgcn_exp2f(s[kt][3]);
         if constexpr (!SUM_MFMA) ps += (p0 + p1) + (p2 + p3);
         pf[kt] = pack4<T>(p0, p1, p2, p3);
       }
@@ -521,12 +503,8 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   };
 
   const int full_tiles = K / WA_KT;
-  if (full_tiles > 0) tile_body(0, std::false_type{}, std::true_type{});
-  for (int tile = 1; tile < full_tiles; ++tile) tile_body(tile, std::false_type{}, std::false_type{});
-  if (full_tiles * WA_KT < K) {
-    if (full_tiles == 0) tile_body(0, std::true_type{}, std::true_type{});
-    else tile_body(full_tiles, std::true_type{}, std::false_type{});
-  }
+  for (int tile = 0; tile < full_tiles; ++tile) tile_body(tile, std::false_type{});
+  if (full_tiles * WA_KT < K) tile_body(full_tiles, std::true_type{});
 
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
