@@ -132,3 +132,43 @@ def test_sync_batchnorm_conversion_is_taken_back():
     assert seq[1].eps == 1e-3 and seq[1].momentum == 0.01
     assert all(a is b for a, b in zip(params, seq.parameters())) and all(a is b for a, b in zip(bufs, seq.buffers()))
     assert list(seq.state_dict().keys()) == keys
+
+
+_REF_ROOT = "/root/reference"
+_GRAFT_PROBE = r"""
+import importlib.util, sys, os
+ref, pkg = sys.argv[1], sys.argv[2]
+sys.path.insert(0, pkg)
+import pointcept.utils                      # this package's overlay (namespace for the two reference files)
+for name in ("misc", "registry"):           # the REFERENCE's registry replaces the overlay's restatement
+    spec = importlib.util.spec_from_file_location(f"pointcept.utils.{name}",
+                                                  os.path.join(ref, "pointcept", "utils", f"{name}.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    setattr(pointcept.utils, name, mod)
+from pointcept.models import build_model, MODELS
+assert type(MODELS).__module__ == "pointcept.utils.registry" and MODELS.__class__.__name__ == "Registry"
+assert sys.modules["pointcept.utils.registry"].__file__.startswith(ref)
+scope = {}
+exec(compile(open(os.path.join(ref, "configs", "my_dataset", "offset_keypoint_ptv3.py")).read(), "cfg", "exec"), scope)
+model = build_model(scope["model"])
+print("\n".join(f"{k} {tuple(v.shape)} {v.dtype}" for k, v in model.state_dict().items()))
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF_ROOT), reason="build container only: needs the reference checkout")
+def test_models_register_with_the_reference_registry_and_build_from_its_config():
+    """INTEGRATION.md's graft, rehearsed: the reference's own Registry class (pointcept/utils/registry.py)
+    takes this package's models, and the reference's training config (configs/my_dataset/
+    offset_keypoint_ptv3.py:11-46) builds the offset model with exactly the reference's state_dict keys and
+    shapes (tests/golden/state_dict_fork_cfg.txt, listed from the reference's own class)."""
+    import subprocess
+    import sys
+    pkg = os.path.join(ROOT, "pointcept-keypointdetection_amd")
+    r = subprocess.run([sys.executable, "-c", _GRAFT_PROBE, _REF_ROOT, pkg], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [l.strip() for l in r.stdout.strip().splitlines() if l.strip()]
+    want = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "state_dict_fork_cfg.txt")) if l.strip()]
+    assert got == want
