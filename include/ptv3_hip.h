@@ -443,6 +443,34 @@ int ptv3_profile_kernel_count(void);
 const char* ptv3_profile_kernel_name(int kernel);
 int ptv3_profile_collect_kernels(double* ms, double* flops, double* bytes, int64_t* launches);
 
+/* ---- Swin3D window partition + cRSE window attention (row A19; PARITY UNPINNED) -----------------------------
+ * The reference computes these through MinkowskiEngine and microsoft/Swin3D, neither of which is in its tree
+ * (SURVEY.md section 8c); oracle/swin3d.py restates them from pointcept/models/swin3d/swin3d_layers.py and the
+ * Swin3D paper and is the only checker these two entry points have.
+ *
+ * ptv3_swin_window_keys replaces the MinkowskiMaxPooling + coordinate_manager.kernel_map part of
+ * BasicLayer.get_map_pair / get_window_mapping (swin3d_layers.py:715-795) and get_shifted_sp (:826-840):
+ * coords (n,4) int32 [batch, x, y, z] at tensor stride `stride`; voxel = floor(c / stride) + shift; window =
+ * floor(voxel / window_size) per axis; key = (batch, window xyz) << 9 | w_w_id with w_w_id = (lx*ws + ly)*ws + lz
+ * (:781-788).  ptv3_argsort_i64(key, end_bit 64) is then the reference's sort by in_map (:752), and
+ * ptv3_pool_segments(key, order, shift 9) yields the windows' token ranges (nempty_num, :777-778).
+ * *bad is set non-zero when a batch index (0..4095) or window coordinate (-4096..4095) does not fit the key. */
+int ptv3_swin_window_keys(const int32_t* coords, int64_t n, int stride, int window_size, int shift, int64_t* key,
+                          int32_t* bad, void* stream);
+/* replaces SelfAttnAIOFunction.apply(..., PosEmb.SEPARATE, TableDims.D0, IndexMode.INDIRECT, ...) at
+ * swin3d_layers.py:556-569, forward only.  q, k, v, out: (n, heads, head_dim) in ORIGINAL voxel order, q already
+ * scaled (:499); {q,k,v}_table: the concatenated fp32 tables of :503-528, table_offsets_host[c] elements per signal
+ * axis c (the reference's `table_offsets`, :441/:452/:464), num_axes = 3, 6 or 9; n2n (n) int64: sorted position ->
+ * original row (n2n_indices); w_start (num_windows + 1) int32: token range of each window in sorted order
+ * (w2n_indices plus the total); n_crse (n, num_axes) fp32 in sorted order (:505-530); max_tokens >= the largest
+ * window (window_size^3 always is).  head_dim 8, 16 or 32.
+ *   e_ij = q_i.k_j + sum_c (q_i.T_K[c][idx] + k_j.T_Q[c][idx]),  out_i = sum_j softmax_j(e_ij) (v_j + sum_c T_V[c][idx]),
+ *   idx = clamp(floor(s_i[c] - s_j[c] + rows_c / 2), 0, rows_c - 1)   in fp32. */
+int ptv3_swin_attn_fwd(const void* q, const void* k, const void* v, const float* q_table, const float* k_table,
+                       const float* v_table, const int32_t* table_offsets_host, int num_axes, const int64_t* n2n,
+                       const int32_t* w_start, int num_windows, const float* n_crse, void* out, int64_t n, int heads,
+                       int head_dim, int max_tokens, int dtype, void* stream);
+
 /* ---- pointops (libs/pointops) ------------------------------------------------------------------
  * Same argument meaning as the reference's extern "C" launchers
  * (libs/pointops/src/knn_query/knn_query_cuda_kernel.h:9-17, grouping/grouping_cuda_kernel.h,

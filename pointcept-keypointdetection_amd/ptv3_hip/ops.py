@@ -656,6 +656,60 @@ def voxel_unique(key):
 
 
 # ---------------------------------------------------------------------------------------------
+# Swin3D window partition + cRSE attention (row A19, parity unpinned: see oracle/swin3d.py)
+# ---------------------------------------------------------------------------------------------
+def swin_window_mapping(coords, stride, window_size, shift=0):
+    """BasicLayer.get_window_mapping (swin3d_layers.py:746-795) of voxels `coords` (n,4) int32 [batch,x,y,z] at tensor
+    stride `stride`, shifted by `shift` voxels (:826-840).  -> w_w_id (n) int64 and w_w_xyz (n,3) int64 in sorted
+    order, w_sizes (W) int64, sort_idx (n) int64, inv_sort_idx (n) int64, w_start (W+1) int32.  One host sync (W)."""
+    _chk(coords, "coords", torch.int32, 2)
+    n = coords.shape[0]
+    key = torch.empty(n, dtype=torch.int64, device=coords.device)
+    bad = torch.empty(1, dtype=torch.int32, device=coords.device)
+    lib.check(lib.ptv3_swin_window_keys(_p(coords), n, int(stride), int(window_size), int(shift), _p(key), _p(bad),
+                                        _stream()), "ptv3_swin_window_keys")
+    order, inverse = argsort_codes(key.view(1, -1), 61)
+    order, inverse = order[0].contiguous(), inverse[0].contiguous()
+    _, w_start, nwin = pool_segments(key, order, 9)
+    if int(bad.item()):
+        raise ValueError("swin_window_mapping: batch index outside 0..4095 or window coordinate outside -4096..4095")
+    w_w_id = key[order] & 511
+    ws = int(window_size)
+    w_w_xyz = torch.stack([w_w_id // ws // ws, w_w_id // ws % ws, w_w_id % ws], dim=-1)
+    w_sizes = (w_start[1:] - w_start[:-1]).long()
+    return w_w_id, w_w_xyz, w_sizes, order, inverse, w_start
+
+
+def swin_attention(q, k, v, q_table, k_table, v_table, table_offsets, n2n, w_start, n_crse, max_tokens):
+    """SelfAttnAIOFunction forward (swin3d_layers.py:556-569): q (pre-scaled), k, v (n, H, D) in original voxel order,
+    concatenated fp32 tables with `table_offsets` elements per signal axis, n2n / w_start / n_crse as
+    swin_window_mapping and WindowAttention.forward build them.  -> (n, H, D) in original order."""
+    _chk(q, "q", _F, 3)
+    for name, t in (("k", k), ("v", v)):
+        _chk(t, name, q.dtype, 3)
+        if t.shape != q.shape:
+            raise ValueError(f"swin_attention: {name} {tuple(t.shape)} vs q {tuple(q.shape)}")
+    for name, t in (("q_table", q_table), ("k_table", k_table), ("v_table", v_table)):
+        _chk(t, name, torch.float32, 1)
+    _chk(n2n, "n2n", torch.int64, 1)
+    _chk(w_start, "w_start", torch.int32, 1)
+    _chk(n_crse, "n_crse", torch.float32, 2)
+    n, heads, hd = q.shape
+    axes = len(table_offsets)
+    total = int(sum(int(t) for t in table_offsets))
+    if n_crse.shape != (n, axes) or n2n.shape[0] != n:
+        raise ValueError(f"swin_attention: n_crse {tuple(n_crse.shape)} / n2n {tuple(n2n.shape)} for {n} voxels, {axes} axes")
+    if min(q_table.numel(), k_table.numel(), v_table.numel()) < total:
+        raise ValueError("swin_attention: tables are shorter than sum(table_offsets)")
+    out = torch.empty_like(q)
+    offs = (ctypes.c_int32 * axes)(*[int(t) for t in table_offsets])
+    lib.check(lib.ptv3_swin_attn_fwd(_p(q), _p(k), _p(v), _p(q_table), _p(k_table), _p(v_table), offs, axes, _p(n2n),
+                                     _p(w_start), w_start.shape[0] - 1, _p(n_crse), _p(out), n, heads, hd,
+                                     int(max_tokens), _dt(q), _stream()), "ptv3_swin_attn_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
 # keypoint aggregation (after the model)
 # ---------------------------------------------------------------------------------------------
 KP_ARGMAX, KP_WEIGHTED, KP_GT_MEAN, KP_GT_FIRST = 0, 1, 2, 3

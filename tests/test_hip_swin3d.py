@@ -1,0 +1,200 @@
+"""Swin3D window partition + cRSE window attention on the GPU (row A19) vs oracle/swin3d.py.
+
+PARITY UNPINNED: the reference runs this path in MinkowskiEngine and microsoft/Swin3D, neither of which is in its
+tree, and it holds no test, fixture or golden vector for it; the oracle restates swin3d_layers.py's index bookkeeping
+and the Swin3D paper's cRSE formula (assumptions listed in its header).  Window partition: exact.  Attention: fp32
+relative L2 <= 1e-4 (the north_star's fp32 budget), bf16 storage <= 2e-2."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import swin3d as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X box"
+    return torch.device("cuda:0")
+
+
+def _voxels(n, extent, seed, batch=1, stride=1, lo=0):
+    rng = np.random.default_rng(seed)
+    c = np.unique(rng.integers(lo, lo + extent, size=(n * 2, 3)), axis=0)
+    c = c[rng.permutation(len(c))[:n]]
+    b = rng.integers(0, batch, size=(len(c), 1))
+    return np.concatenate([b, c * stride], axis=1).astype(np.int32)
+
+
+def _surface(n, extent, seed):
+    """Voxels on a wavy sheet: windows hold a realistic 20-60 of their 125 / 343 cells."""
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, extent, size=(3 * n, 2))
+    z = extent / 2 + extent / 6 * np.sin(xy[:, 0] / 9.0) * np.cos(xy[:, 1] / 7.0) + rng.normal(0, 0.4, 3 * n)
+    g = np.unique(np.floor(np.concatenate([xy, z[:, None]], 1)).astype(np.int64), axis=0)
+    g = g[rng.permutation(len(g))[:n]]
+    return np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+
+
+@pytest.mark.parametrize("ws,shift,stride,lo,batch", [(5, 0, 1, 0, 1), (5, 2, 1, 0, 3), (7, 3, 2, -60, 2), (3, 1, 4, -9, 2),
+                                                       (8, 4, 1, 0, 1)])
+def test_window_mapping_exact(dev, ws, shift, stride, lo, batch):
+    from ptv3_hip import ops
+    c = _voxels(5000, 48, ws * 10 + shift, batch=batch, stride=stride, lo=lo)
+    w_w_id, w_w_xyz, nempty, sort_idx, inv = O.window_mapping(c, stride, ws, shift)
+    g = ops.swin_window_mapping(torch.from_numpy(c).to(dev), stride, ws, shift)
+    gw_id, gw_xyz, gsizes, gsort, ginv, gstart = (t.cpu().numpy() for t in g)
+    assert np.array_equal(gw_id, w_w_id) and np.array_equal(gw_xyz, w_w_xyz)
+    assert np.array_equal(gsizes, nempty) and np.array_equal(gsort, sort_idx) and np.array_equal(ginv, inv)
+    assert np.array_equal(gstart, np.concatenate([[0], np.cumsum(nempty)]))
+
+
+def test_window_mapping_rejects_coordinates_outside_the_key(dev):
+    from ptv3_hip import ops
+    c = np.array([[0, 0, 0, 0], [0, 5 * 5000, 0, 0]], np.int32)
+    with pytest.raises(ValueError, match="window coordinate"):
+        ops.swin_window_mapping(torch.from_numpy(c).to(dev), 1, 5, 0)
+    with pytest.raises(RuntimeError, match="window_size"):
+        ops.swin_window_mapping(torch.from_numpy(c).to(dev), 1, 9, 0)
+
+
+def _case(coords, heads, hd, ws, quant, crse, seed, shift=0, table_std=0.3):
+    rng = np.random.default_rng(seed)
+    n = len(coords)
+    w_w_id, w_w_xyz, nempty, sort_idx, _ = O.window_mapping(coords, 1, ws, shift)
+    nsig = {"XYZ": 0, "XYZ_RGB": 3, "XYZ_RGB_NORM": 6}[crse]
+    sig = rng.uniform(-1, 1, (n, nsig)).astype(np.float32)
+    if nsig:
+        sig[:4, :3] = [[-1, -1, -1], [1, 1, 1], [1, -1, 1], [-1, 1, -1]]        # the +-2 differences that need the clamp
+    nc = O.n_coords(w_w_xyz, rng.random((n, 3), dtype=np.float32), sig, sort_idx)
+    rows = O.table_lengths(ws, quant, crse)
+    offs = [r * heads * hd for r in rows for _ in range(3)]
+    tabs = [rng.normal(0, table_std, sum(offs)).astype(np.float32) for _ in range(3)]
+    q, k, v = (rng.normal(size=(n, heads, hd)).astype(np.float32) for _ in range(3))
+    q *= hd ** -0.5
+    _, _, _, w_sizes, w2n, _ = O.sparse_self_attention(nempty)
+    return q, k, v, tabs, offs, w_sizes, w2n, sort_idx, O.n_crse(nc, quant, crse)
+
+
+def _run(dev, case, ws, dtype=torch.float32):
+    from ptv3_hip import ops
+    q, k, v, tabs, offs, w_sizes, w2n, n2n, cr = case
+    t = lambda a, d=None: torch.from_numpy(np.ascontiguousarray(a)).to(dev) if d is None else \
+        torch.from_numpy(np.ascontiguousarray(a)).to(dev).to(d)
+    w_start = np.concatenate([w2n, [len(q)]]).astype(np.int32)
+    out = ops.swin_attention(t(q, dtype), t(k, dtype), t(v, dtype), t(tabs[0]), t(tabs[1]), t(tabs[2]), offs,
+                             t(n2n.astype(np.int64)), t(w_start), t(cr), ws ** 3)
+    torch.cuda.synchronize()
+    return out.float().cpu().numpy()
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.mark.parametrize("heads,hd,ws,quant,crse", [(6, 8, 5, 4, "XYZ_RGB_NORM"), (6, 16, 7, 4, "XYZ_RGB_NORM"),
+                                                     (4, 16, 5, 50, "XYZ_RGB"), (2, 32, 5, 4, "XYZ"),
+                                                     (3, 16, 3, 2, "XYZ_RGB_NORM")])
+def test_crse_attention_fp32(dev, heads, hd, ws, quant, crse):
+    coords = _surface(4000, 60, heads * 100 + hd)
+    case = _case(coords, heads, hd, ws, quant, crse, seed=hd + ws)
+    want = O.crse_attention(*case[:3], *case[3], *case[4:])
+    got = _run(dev, case, ws)
+    assert _rel(got, want) <= 1e-4, _rel(got, want)
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_crse_attention_dense_windows_and_shift(dev):
+    """Fully occupied 7^3 windows (343 tokens: six key chunks per wave, the largest LDS footprint) on the shifted
+    partition, plus windows of a single voxel."""
+    g = np.stack(np.meshgrid(np.arange(15), np.arange(14), np.arange(12), indexing="ij"), -1).reshape(-1, 3)
+    lone = np.array([[200, 200, 200], [300, 10, 50]])
+    coords = np.concatenate([np.zeros((len(g) + 2, 1), np.int64), np.concatenate([g, lone])], 1).astype(np.int32)
+    case = _case(coords, 2, 16, 7, 4, "XYZ_RGB_NORM", seed=7, shift=3)
+    assert case[5].max() == 343 and case[5].min() == 1
+    want = O.crse_attention(*case[:3], *case[3], *case[4:])
+    got = _run(dev, case, 7)
+    assert _rel(got, want) <= 1e-4, _rel(got, want)
+
+
+def test_crse_attention_bf16_storage(dev):
+    coords = _surface(3000, 50, 5)
+    case = _case(coords, 6, 16, 5, 4, "XYZ_RGB_NORM", seed=11)
+    rb = lambda a: torch.from_numpy(a).bfloat16().float().numpy()
+    want = O.crse_attention(rb(case[0]), rb(case[1]), rb(case[2]), *case[3], *case[4:])
+    got = _run(dev, case, 5, torch.bfloat16)
+    assert _rel(got, want) <= 1e-2, _rel(got, want)       # one bf16 rounding of the output
+
+
+def test_crse_attention_argument_checks(dev):
+    from ptv3_hip import ops
+    coords = _surface(500, 30, 1)
+    case = _case(coords, 3, 12, 5, 4, "XYZ", seed=1)
+    with pytest.raises(RuntimeError, match="head_dim"):
+        _run(dev, case, 5)
+    case = _case(coords, 3, 16, 5, 4, "XYZ", seed=1)
+    q, k, v, tabs, offs, w_sizes, w2n, n2n, cr = case
+    with pytest.raises(RuntimeError, match="table_offsets"):
+        _run(dev, (q, k, v, tabs, [o - 16 for o in offs], w_sizes, w2n, n2n, cr), 5)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.swin_attention(torch.zeros(4, 3, 16), torch.zeros(4, 3, 16), torch.zeros(4, 3, 16), torch.zeros(8),
+                           torch.zeros(8), torch.zeros(8), offs, torch.zeros(4, dtype=torch.int64),
+                           torch.zeros(2, dtype=torch.int32), torch.zeros(4, 3), 125)
+
+
+def _np_ln(x, g, b, eps=1e-5):
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * g + b
+
+
+def _np_gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+def test_window_stage_two_blocks_regular_then_shifted(dev):
+    """WindowStage = the block loop of BasicLayer (swin3d_layers.py:846-866): block 0 on the regular partition,
+    block 1 on the half-window shift, each LN -> cRSE attention -> proj -> residual -> LN -> MLP -> residual
+    (:619-630), against the same composition of oracle pieces in float64 / fp32."""
+    from pointcept.models.swin3d import WindowStage
+    torch.manual_seed(3)
+    dim, heads, ws, quant, crse = 48, 6, 5, 4, "XYZ_RGB_NORM"
+    stage = WindowStage(dim, 2, heads, ws, quant, cRSE=crse)
+    with torch.no_grad():
+        for name, p in stage.named_parameters():
+            if name.endswith("_table"):
+                p.normal_(0, 0.2)                     # the 0.02 initialisation would hide an indexing error
+            elif name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+                p.uniform_(0.5, 1.5)
+            elif name.endswith("bias"):
+                p.normal_(0, 0.1)
+    stage = stage.to(dev).eval()
+    coords = _surface(3000, 50, 9)
+    n = len(coords)
+    rng = np.random.default_rng(0)
+    local = rng.random((n, 3), dtype=np.float32)
+    sig = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+    feats = rng.normal(size=(n, dim)).astype(np.float32)
+    with torch.no_grad():
+        got = stage(torch.from_numpy(feats).to(dev), torch.from_numpy(coords).to(dev), 1,
+                    torch.from_numpy(local).to(dev), torch.from_numpy(sig).to(dev)).cpu().numpy()
+    sd = {k: v.detach().cpu().numpy() for k, v in stage.state_dict().items()}
+    x = feats.astype(np.float64)
+    for i, shift in enumerate((0, ws // 2)):
+        pre = f"blocks.{i}."
+        w_w_id, w_w_xyz, nempty, sort_idx, _ = O.window_mapping(coords, 1, ws, shift)
+        nc = O.n_coords(w_w_xyz, local, sig, sort_idx)
+        args = (*O.sparse_self_attention(nempty)[:3], nempty, O.sparse_self_attention(nempty)[4], sort_idx, None, nc)
+        params = {k[len(pre) + 5:]: v for k, v in sd.items() if k.startswith(pre + "attn.")}
+        h = _np_ln(x, sd[pre + "norm1.weight"], sd[pre + "norm1.bias"]).astype(np.float32)
+        x = x + O.window_attention_forward(params, h, args, heads, quant, crse)
+        h = _np_ln(x, sd[pre + "norm2.weight"], sd[pre + "norm2.bias"])
+        h = _np_gelu(h @ sd[pre + "mlp.fc1.weight"].T.astype(np.float64) + sd[pre + "mlp.fc1.bias"])
+        x = x + h @ sd[pre + "mlp.fc2.weight"].T.astype(np.float64) + sd[pre + "mlp.fc2.bias"]
+    assert _rel(got, x) <= 1e-4, _rel(got, x)
+    stage.train()
+    with pytest.raises(NotImplementedError, match="forward only"):
+        stage(torch.from_numpy(feats).to(dev), torch.from_numpy(coords).to(dev), 1, torch.from_numpy(local).to(dev),
+              torch.from_numpy(sig).to(dev))

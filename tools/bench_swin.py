@@ -1,0 +1,69 @@
+"""Time ptv3_swin_attn_fwd (Swin3D cRSE window attention, row A19) on S3DIS-like stages.
+usage: python tools/bench_swin.py [n_voxels]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pointcept-keypointdetection_amd"))
+from ptv3_hip import ops  # noqa: E402
+
+
+def surface(n, extent, seed):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, extent, size=(3 * n, 2))
+    z = extent / 2 + 6.0 * np.sin(xy[:, 0] / 19.0) * np.cos(xy[:, 1] / 17.0) + rng.normal(0, 0.4, 3 * n)   # a room-like sheet
+    g = np.unique(np.floor(np.concatenate([xy, z[:, None]], 1)).astype(np.int64), axis=0)
+    g = g[rng.permutation(len(g))[:n]]
+    return np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+    dev = torch.device("cuda:0")
+    extent = int((n / 1.2) ** 0.5)
+    coords = torch.from_numpy(surface(n, extent, 0)).to(dev)
+    n = coords.shape[0]
+    g = torch.Generator(device=dev).manual_seed(0)
+    for heads, hd, ws, quant, crse, dtype in ((6, 8, 5, 4, "XYZ_RGB_NORM", torch.float32),
+                                              (6, 16, 7, 4, "XYZ_RGB_NORM", torch.float32),
+                                              (6, 16, 7, 4, "XYZ_RGB_NORM", torch.bfloat16),
+                                              (4, 16, 5, 50, "XYZ_RGB", torch.float32)):
+        t0 = time.perf_counter()
+        w_w_id, w_w_xyz, w_sizes, n2n, inv, w_start = ops.swin_window_mapping(coords, 1, ws, 0)
+        torch.cuda.synchronize()
+        t_map = (time.perf_counter() - t0) * 1e3
+        nsig = {"XYZ": 3, "XYZ_RGB": 6, "XYZ_RGB_NORM": 9}[crse]
+        rows = [2 * ws * quant] + [2 * 2 * quant * 2] * (nsig // 3 - 1)
+        offs = [r * heads * hd for r in rows for _ in range(3)]
+        tabs = [torch.randn(sum(offs), device=dev, generator=g) * 0.02 for _ in range(3)]
+        q, k, v = (torch.randn(n, heads, hd, device=dev, generator=g).to(dtype) for _ in range(3))
+        sig = torch.rand(n, nsig, device=dev, generator=g)
+        sig[:, :3] = w_w_xyz.float() + sig[:, :3]
+        sig[:, 3:] = sig[:, 3:] * 2 - 1
+        scale = torch.tensor([quant] * 3 + [quant * 2] * (nsig - 3), device=dev, dtype=torch.float32)
+        cr = (sig * scale).contiguous()
+        run = lambda: ops.swin_attention(q, k, v, *tabs, offs, n2n, w_start, cr, ws ** 3)
+        for _ in range(3):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        pairs = float((w_sizes.double() ** 2).sum().item()) * heads
+        print(json.dumps({"op": "swin_attn_fwd", "voxels": n, "windows": int(w_sizes.numel()),
+                          "mean_tokens": round(float(w_sizes.double().mean().item()), 1),
+                          "max_tokens": int(w_sizes.max().item()), "heads": heads, "head_dim": hd, "window": ws,
+                          "quant": quant, "crse": crse, "dtype": str(dtype).split(".")[-1], "ms": round(ms, 3),
+                          "Gpairs_per_s": round(pairs / ms / 1e6, 2), "mapping_ms_cold": round(t_map, 2)}))
+
+
+if __name__ == "__main__":
+    main()
