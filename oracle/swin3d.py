@@ -161,3 +161,159 @@ def window_attention_forward(params, feats, attn_args, num_heads, quant_size, cr
         offs += [int(np.prod(shp[1:]))] * 3
     o = crse_attention(q, k, v, qt, kt, vt, offs, w_sizes, w2n, n2n, n_crse(ncoords, quant_size, crse))
     return o.reshape(nv, dim) @ params["proj.weight"].T + params["proj.bias"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole Swin3DUNet forward (swin3d_v1m1_base.py:149-244), eval mode, state_dict driven
+# ---------------------------------------------------------------------------------------------------------------
+def _ln(x, g, b, eps=1e-5):
+    x = x.astype(np.float64)
+    mu = x.mean(-1, keepdims=True)
+    var = ((x - mu) ** 2).mean(-1, keepdims=True)
+    return (x - mu) / np.sqrt(var + eps) * g + b
+
+
+def _gelu(x):
+    from scipy.special import erf
+    return 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+
+
+def _bn(x, sd, pre, eps=1e-5):
+    return (x - sd[pre + "running_mean"]) / np.sqrt(sd[pre + "running_var"].astype(np.float64) + eps) * \
+        sd[pre + "weight"] + sd[pre + "bias"]
+
+
+def _unique_cells(batch, cell):
+    """Sorted distinct (batch, cell) rows -> (first member of each in sorted order, cell id of every row, counts)."""
+    rows = np.concatenate([batch[:, None], cell], axis=1)
+    uniq, inverse, counts = np.unique(rows, axis=0, return_inverse=True, return_counts=True)
+    return uniq, inverse.reshape(-1), counts
+
+
+def _offset_of(batch, nb):
+    return np.cumsum(np.bincount(batch, minlength=nb)).astype(np.int32)
+
+
+class Swin3DOracle:
+    """Functional restatement of Swin3DUNet.forward for knn_down=True, stem_transformer=True.  Sparse tensors are
+    (coords int (n,4) at a tensor stride, feat (n,C), cfeat (n, 4 + signals)) triples numbered in sorted
+    (batch, x, y, z) order; see the header of this file and of the product's swin3d_v1m1_base.py for the choices the
+    absent libraries leave open (tap order of the stem kernel, Euclidean KNN distance, the GridCoordsDown tie rule)."""
+
+    def __init__(self, state_dict, cfg):
+        self.sd = {k: np.asarray(v, np.float32) if np.asarray(v).dtype.kind == "f" else np.asarray(v)
+                   for k, v in state_dict.items()}
+        self.cfg = cfg
+
+    # ---- pieces -------------------------------------------------------------------------------------------
+    def _lin(self, x, pre):
+        y = x.astype(np.float64) @ self.sd[pre + "weight"].T.astype(np.float64)
+        return y + self.sd[pre + "bias"] if pre + "bias" in self.sd else y
+
+    def _stage(self, pre, feat, coords, stride, cfeat, depth, heads, ws):
+        quant, crse = self.cfg["quant_size"], self.cfg["cRSE"]
+        local = (cfeat[:, 1:4] - coords[:, 1:].astype(np.float32)) / np.float32(stride)
+        sig = cfeat[:, 4:]
+        x = feat.astype(np.float64)
+        for i in range(depth):
+            shift = 0 if i % 2 == 0 else ws // 2
+            _, w_w_xyz, nempty, sort_idx, _ = window_mapping(coords, stride, ws, shift)
+            nc = n_coords(w_w_xyz, local, sig, sort_idx)
+            _, _, _, w_sizes, w2n, _ = sparse_self_attention(nempty)
+            args = (None, None, None, w_sizes, w2n, sort_idx, None, nc)
+            b = f"{pre}blocks.{i}."
+            params = {k[len(b) + 5:]: v for k, v in self.sd.items() if k.startswith(b + "attn.")}
+            h = _ln(x, self.sd[b + "norm1.weight"], self.sd[b + "norm1.bias"]).astype(np.float32)
+            x = x + window_attention_forward(params, h, args, heads, quant, crse)
+            h = _ln(x, self.sd[b + "norm2.weight"], self.sd[b + "norm2.bias"])
+            x = x + self._lin(_gelu(self._lin(h, b + "mlp.fc1.")), b + "mlp.fc2.")
+        return x.astype(np.float32)
+
+    def _down(self, pre, coords, stride, feat, cfeat, offset, down):
+        from . import pointops as OP
+        new_stride = stride * down
+        uniq, cell, counts = _unique_cells(coords[:, 0], coords[:, 1:] // new_stride)
+        m = len(uniq)
+        new_coords = np.concatenate([uniq[:, :1], uniq[:, 1:] * new_stride], axis=1).astype(np.int64)
+        mean = np.zeros((m, cfeat.shape[1]), np.float64)
+        np.add.at(mean, cell, cfeat.astype(np.float64))
+        mean /= counts[:, None]
+        dist = np.sqrt(((mean[cell] - cfeat) ** 2).sum(1))
+        best = np.full(m, np.inf)
+        np.minimum.at(best, cell, dist)
+        near = dist <= best[cell] * (1 + 1e-4) + 1e-12
+        pick = np.full(m, len(dist), np.int64)
+        np.minimum.at(pick, cell, np.where(near, np.arange(len(dist)), len(dist)))
+        new_cfeat = cfeat[pick]
+        new_offset = _offset_of(new_coords[:, 0], len(offset))
+        y = self._lin(_ln(feat, self.sd[pre + "norm.weight"], self.sd[pre + "norm.bias"]), pre + "linear.")
+        idx, _ = OP.knn_query(16, np.ascontiguousarray(cfeat[:, 1:4]), offset,
+                              np.ascontiguousarray(new_cfeat[:, 1:4]), new_offset)
+        idx = np.where(idx < 0, idx[:, :1], idx)
+        new_feat = y[idx].max(axis=1).astype(np.float32)
+        return new_coords, new_stride, new_feat, new_cfeat, new_offset
+
+    def _up(self, pre, deep, shallow, heads, ws):
+        from . import pointops as OP
+        (dc, ds, dfeat, dcf, doff), (sc, ss, sfeat, scf, soff) = deep, shallow
+        y2 = self._lin(_ln(dfeat, self.sd[pre + "linear2.0.weight"], self.sd[pre + "linear2.0.bias"]), pre + "linear2.1.")
+        idx, dist = OP.knn_query(self.cfg["up_k"], np.ascontiguousarray(dcf[:, 1:4]), doff,
+                                 np.ascontiguousarray(scf[:, 1:4]), soff)
+        w = 1.0 / (np.sqrt(dist.astype(np.float32)) + np.float32(1e-8))   # Euclidean, as libs/pointops returns it
+        w = w / w.sum(1, keepdims=True)
+        carried = (y2[idx] * w[:, :, None]).sum(1)
+        feat = self._lin(_ln(sfeat, self.sd[pre + "linear1.0.weight"], self.sd[pre + "linear1.0.bias"]),
+                         pre + "linear1.1.") + carried
+        feat = feat.astype(np.float32)
+        if "attn" in self.cfg["upsample"] and ws > 0:
+            feat = self._stage(pre + "block.", feat, sc, ss, scf, 1, heads, ws)
+        return sc, ss, feat, scf, soff
+
+    # ---- forward -------------------------------------------------------------------------------------------
+    def forward(self, data, trace=None):
+        import torch
+        trace = {} if trace is None else trace
+        from .ptv3 import subm_conv3d
+        cfg, sd = self.cfg, self.sd
+        coord, feat, coord_feat = (np.asarray(data[k], np.float32) for k in ("coord", "feat", "coord_feat"))
+        grid = np.asarray(data["grid_coord"], np.int64)
+        offset = np.asarray(data["offset"], np.int64)
+        batch = np.repeat(np.arange(len(offset)), np.diff(np.concatenate([[0], offset])))
+        rows = np.concatenate([batch[:, None].astype(np.float32), coord / np.float32(cfg["base_grid_size"]),
+                               coord_feat / np.float32(1.001), feat], axis=1)
+        uniq, p2v, counts = _unique_cells(batch, grid)
+        mean = np.zeros((len(uniq), rows.shape[1]), np.float64)
+        np.add.at(mean, p2v, rows.astype(np.float64))
+        mean = (mean / counts[:, None]).astype(np.float32)
+        ncf = coord_feat.shape[1] + 4
+        coords, stride, cfeat, x = uniq.astype(np.int64), 1, mean[:, :ncf], mean[:, ncf:]
+        off = _offset_of(coords[:, 0], len(offset))
+        # stem: 3x3x3 convolution on the occupied voxels, kernel[t] at offset t = (dx+1) + 3 (dy+1) + 9 (dz+1)
+        kern = sd["stem_layer.conv_layers.0.kernel"]
+        cin, cout = kern.shape[1:]
+        w = np.zeros((cout, 3, 3, 3, cin), np.float32)
+        for a in range(3):
+            for b in range(3):
+                for c in range(3):
+                    w[:, a, b, c, :] = kern[a + 3 * b + 9 * c].T
+        y = subm_conv3d(torch.from_numpy(x), torch.from_numpy(coords), torch.from_numpy(w)).numpy()
+        x = np.maximum(_bn(y, sd, "stem_layer.conv_layers.1.bn.", 1e-5), 0).astype(np.float32)
+        trace["stem"] = x
+        skips = []
+        nl = cfg["num_layers"]
+        for i in range(nl):
+            pre = f"layers.{i}."
+            x = self._stage(pre, x, coords, stride, cfeat, cfg["depths"][i], cfg["num_heads"][i], cfg["window_sizes"][i])
+            skips.append((coords, stride, x, cfeat, off))
+            trace[f"layer{i}"] = x
+            if i < nl - 1:
+                coords, stride, x, cfeat, off = self._down(pre + "downsample.", coords, stride, x, cfeat, off,
+                                                           cfg["down_stride"] if i == 0 else 2)
+                trace[f"down{i}"], trace[f"down{i}_cfeat"] = x, cfeat
+        level = skips.pop()
+        for j, i in enumerate(range(nl - 1, 0, -1)):
+            level = self._up(f"upsamples.{j}.", level, skips.pop(), cfg["num_heads"][i - 1], cfg["window_sizes"][i - 1])
+            trace[f"up{j}"] = level[2]
+        h = self._lin(level[2], "classifier.0.")
+        h = np.maximum(_bn(h, sd, "classifier.1.", 1e-5), 0)
+        return self._lin(h, "classifier.3.")[p2v].astype(np.float32)

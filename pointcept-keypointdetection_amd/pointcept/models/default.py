@@ -36,6 +36,27 @@ def _full_resolution(point):
 
 
 @MODELS.register_module()
+class DefaultSegmentor(nn.Module):
+    """default.py:14-37: a backbone that returns per-point logits itself (Swin3D-v1m1 is built this way,
+    configs/s3dis/semseg-swin3d-v1m1-0-small.py:9-31)."""
+
+    def __init__(self, backbone=None, criteria=None):
+        super().__init__()
+        self.backbone = build_model(backbone)
+        self.criteria = build_criteria(criteria)
+
+    def forward(self, input_dict):
+        if "condition" in input_dict.keys():
+            input_dict["condition"] = input_dict["condition"][0]
+        seg_logits = self.backbone(input_dict)
+        if self.training:
+            return dict(loss=self.criteria(seg_logits, input_dict["segment"]))
+        if "segment" in input_dict.keys():
+            return dict(loss=self.criteria(seg_logits, input_dict["segment"]), seg_logits=seg_logits)
+        return dict(seg_logits=seg_logits)
+
+
+@MODELS.register_module()
 class DefaultSegmentorV2(nn.Module):
     def __init__(self, num_classes, backbone_out_channels, backbone=None, criteria=None, freeze_backbone=False):
         super().__init__()

@@ -35,3 +35,29 @@ TINY_M2_CFG = dict(
     drop_path=0.3, layer_scale=0.5, shuffle_orders=True, pre_norm=True, enable_rpe=False, enable_flash=False,
     upcast_attention=False, upcast_softmax=False,
 )
+
+# Swin3D-S backbone of configs/s3dis/semseg-swin3d-v1m1-0-small.py:11-30 (built there under "DefaultSegmentor")
+SWIN3D_S3DIS_CFG = dict(
+    type="Swin3D-v1m1", in_channels=9, num_classes=13, base_grid_size=0.02, depths=[2, 4, 9, 4, 4],
+    channels=[48, 96, 192, 384, 384], num_heads=[6, 6, 12, 24, 24], window_sizes=[5, 7, 7, 7, 7], quant_size=4,
+    drop_path_rate=0.3, up_k=3, num_layers=5, stem_transformer=True, down_stride=3, upsample="linear_attn",
+    knn_down=True, cRSE="XYZ_RGB_NORM", fp16_mode=1,
+)
+
+# the fork's Swin3D offset model (configs/my_dataset/offset_keypoint_swin3d.py:11-40)
+OFFSET_SWIN3D_CFG = dict(
+    type="OffsetKeypointSwin3D", num_keypoints=6, hidden_dim=256,
+    backbone_conf=dict(
+        type="Swin3D-v1m1", in_channels=4, num_classes=64, base_grid_size=0.02, quant_size=50, num_layers=4,
+        depths=[2, 2, 6, 2], channels=[64, 128, 256, 512], num_heads=[4, 8, 16, 32], window_sizes=[5, 7, 7, 7],
+        up_k=3, drop_path_rate=0.2, stem_transformer=True, down_stride=2, upsample="linear", knn_down=True,
+        cRSE="XYZ_RGB", fp16_mode=1,
+    ),
+)
+
+# plumbing-size Swin3D: three levels, both head widths the kernel is built for (8 and 16)
+TINY_SWIN3D_CFG = dict(
+    type="Swin3D-v1m1", in_channels=9, num_classes=13, base_grid_size=0.02, depths=[2, 2, 2], channels=[16, 32, 32],
+    num_heads=[2, 2, 2], window_sizes=[5, 7, 7], quant_size=4, drop_path_rate=0.3, up_k=3, num_layers=3,
+    stem_transformer=True, down_stride=3, upsample="linear_attn", knn_down=True, cRSE="XYZ_RGB_NORM", fp16_mode=1,
+)

@@ -172,3 +172,30 @@ def test_models_register_with_the_reference_registry_and_build_from_its_config()
     got = [l.strip() for l in r.stdout.strip().splitlines() if l.strip()]
     want = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", "state_dict_fork_cfg.txt")) if l.strip()]
     assert got == want
+
+
+@pytest.mark.parametrize("cfg_name,listing", [("SWIN3D_S3DIS_CFG", "state_dict_swin3d_s3dis.txt"),
+                                              ("OFFSET_SWIN3D_CFG", "state_dict_offset_swin3d.txt")])
+def test_swin3d_state_dict_matches_the_reference_classes(cfg_name, listing):
+    """Keys, shapes, dtypes and order of "Swin3D-v1m1" / "OffsetKeypointSwin3D" against listings taken from the
+    reference's own constructors (tests/golden/make_golden_swin3d.py; its header names the two stem modules whose keys
+    come from a MinkowskiEngine stand-in).  The configs restate configs/s3dis/semseg-swin3d-v1m1-0-small.py:11-30 and
+    configs/my_dataset/offset_keypoint_swin3d.py:11-40."""
+    from ptv3_hip import configs
+    from pointcept.models import build_model
+    model = build_model(getattr(configs, cfg_name))
+    got = [f"{k} {tuple(v.shape)} {v.dtype}" for k, v in model.state_dict().items()]
+    want = [l.strip() for l in open(os.path.join(ROOT, "tests", "golden", listing)) if l.strip()]
+    assert got == want
+
+
+def test_swin3d_refuses_what_it_does_not_build():
+    from ptv3_hip import configs
+    from pointcept.models import build_model
+    with pytest.raises(NotImplementedError, match="knn_down=False"):
+        build_model(dict(configs.TINY_SWIN3D_CFG, knn_down=False))
+    with pytest.raises(NotImplementedError, match="stem_transformer=False"):
+        build_model(dict(configs.TINY_SWIN3D_CFG, stem_transformer=False))
+    model = build_model(configs.TINY_SWIN3D_CFG).train()
+    with pytest.raises(NotImplementedError, match="forward only"):
+        model({})

@@ -198,3 +198,119 @@ def test_window_stage_two_blocks_regular_then_shifted(dev):
     with pytest.raises(NotImplementedError, match="forward only"):
         stage(torch.from_numpy(feats).to(dev), torch.from_numpy(coords).to(dev), 1, torch.from_numpy(local).to(dev),
               torch.from_numpy(sig).to(dev))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole model
+# ---------------------------------------------------------------------------------------------------------------
+def _swin_batch(sizes, seed, sig_dim=6, feat_dim=9, grid=0.02, dup=0.15):
+    """Scenes on wavy sheets.  coord = (voxel + sub-voxel offset) * grid, so coord / base_grid_size - grid_coord is the
+    sub-voxel offset the cRSE expects; `dup` of the voxels hold two points (voxel averaging, :162-181)."""
+    rng = np.random.default_rng(seed)
+    coords, grids, feats, sigs, offs = [], [], [], [], []
+    total = 0
+    for b, n in enumerate(sizes):
+        g = _surface(n, 46, seed * 10 + b)[:, 1:].astype(np.int64)
+        extra = g[rng.random(len(g)) < dup]
+        g = np.concatenate([g, extra])
+        g = g[rng.permutation(len(g))]
+        p = (g + rng.random(g.shape)) * grid
+        s = rng.uniform(-1, 1, (len(g), sig_dim))
+        grids.append(g)
+        coords.append(p)
+        sigs.append(s)
+        feats.append(rng.normal(size=(len(g), feat_dim)))
+        total += len(g)
+        offs.append(total)
+    return {"coord": np.concatenate(coords).astype(np.float32), "grid_coord": np.concatenate(grids),
+            "feat": np.concatenate(feats).astype(np.float32), "coord_feat": np.concatenate(sigs).astype(np.float32),
+            "offset": np.asarray(offs, np.int64)}
+
+
+def _randomise(model, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("_table"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            elif name.endswith("kernel"):
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / (p.shape[0] * p.shape[1])) ** 0.5)
+            elif p.dim() == 2:
+                p.copy_(torch.randn(p.shape, generator=g) * (1.0 / p.shape[1]) ** 0.5)
+            elif name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+            else:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+        for name, b in model.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif name.endswith("running_var"):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+
+def _to_dev(batch, dev):
+    return {k: torch.from_numpy(v).to(dev) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("upsample", ["linear_attn", "linear"])
+def test_swin3d_unet_forward_matches_the_restated_model(dev, upsample):
+    """"Swin3D-v1m1" end to end (voxel averaging, stem convolution, regular / shifted cRSE attention stages, KNN
+    downsampling with the nearest-to-mean signal carrier, 3-NN upsampling with and without its attention block,
+    classifier, slice back to the points) against oracle/swin3d.py's Swin3DOracle.  PARITY UNPINNED (see the oracle)."""
+    from ptv3_hip import configs
+    from pointcept.models import build_model
+    cfg = dict(configs.TINY_SWIN3D_CFG, upsample=upsample)
+    model = build_model(cfg)
+    _randomise(model, 5)
+    batch = _swin_batch([2600, 1500], seed=3)
+    oracle = O.Swin3DOracle({k: v.numpy() for k, v in model.state_dict().items()}, cfg)
+    want = oracle.forward(batch)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        got = model(_to_dev(batch, dev)).float().cpu().numpy()
+    assert got.shape == want.shape == (len(batch["coord"]), 13)
+    assert _rel(got, want) <= 1e-4, _rel(got, want)
+    # two points of one voxel receive the same row (sp.slice(in_field))
+    key = np.concatenate([np.repeat(np.arange(2), np.diff(np.concatenate([[0], batch["offset"]])))[:, None],
+                          batch["grid_coord"]], 1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    twin = np.nonzero(cnt[inv.reshape(-1)] > 1)[0]
+    assert len(twin) > 100
+    first = {}
+    for i in twin:
+        j = first.setdefault(int(inv.reshape(-1)[i]), i)
+        assert np.array_equal(got[i], got[j])
+
+
+def test_offset_keypoint_swin3d_wrapper(dev):
+    """The fork's wrapper (offset_keypoint_swin3d.py): coord_feat derived from feat, XYZ_RGB cRSE over a 4-channel
+    signal (normals + curvature: the attention reads the first three), head + sigmoid on the score, loss when the
+    batch carries a target."""
+    from pointcept.models import build_model
+    cfg = dict(type="OffsetKeypointSwin3D", num_keypoints=6, hidden_dim=32,
+               backbone_conf=dict(type="Swin3D-v1m1", in_channels=4, num_classes=32, base_grid_size=0.02, quant_size=50,
+                                  num_layers=3, depths=[2, 2, 2], channels=[32, 32, 64], num_heads=[2, 2, 4],
+                                  window_sizes=[5, 7, 7], up_k=3, drop_path_rate=0.2, stem_transformer=True,
+                                  down_stride=2, upsample="linear", knn_down=True, cRSE="XYZ_RGB", fp16_mode=1))
+    model = build_model(cfg)
+    _randomise(model, 9)
+    batch = _swin_batch([2200, 1800], seed=6, sig_dim=4, feat_dim=4, dup=0.0)
+    batch["feat"] = np.clip(batch.pop("coord_feat"), -1, 1)          # the wrapper builds coord_feat from feat
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    oracle = O.Swin3DOracle({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")},
+                            cfg["backbone_conf"])
+    f = oracle.forward(dict(batch, coord_feat=batch["feat"])).astype(np.float64)
+    h = f @ sd["head.0.weight"].T + sd["head.0.bias"]
+    h = (h - sd["head.1.running_mean"]) / np.sqrt(sd["head.1.running_var"] + 1e-5) * sd["head.1.weight"] + sd["head.1.bias"]
+    want = (np.maximum(h, 0) @ sd["head.3.weight"].T + sd["head.3.bias"]).reshape(-1, 6, 4)
+    want[..., 3] = 1 / (1 + np.exp(-want[..., 3]))
+    rng = np.random.default_rng(0)
+    target = np.concatenate([rng.normal(size=(len(f), 6, 3)), (rng.random((len(f), 6, 1)) > 0.5)], -1).astype(np.float32)
+    model = model.to(dev).eval()
+    data = _to_dev(batch, dev)
+    data["target"] = torch.from_numpy(target).to(dev)
+    with torch.no_grad():
+        out = model(data)
+    got = out["pred"].cpu().numpy()
+    assert _rel(got, want) <= 1e-4, _rel(got, want)
+    assert "coord_feat" in data and torch.isfinite(out["loss"])

@@ -22,9 +22,41 @@ def surface(n, extent, seed):
     return np.concatenate([np.zeros((len(g), 1), np.int64), g], 1).astype(np.int32)
 
 
+def bench_model(n, dev):
+    """Whole "Swin3D-v1m1" forward, Swin3D-S / S3DIS config (BASELINE configs[4] shape: 9 input channels, colour +
+    normal signals, 5^3 / 7^3 windows), one scene of n points on a room-like sheet, random weights, fp32."""
+    from ptv3_hip import configs
+    from pointcept.models import build_model
+    rng = np.random.default_rng(0)
+    extent = int((n / 1.2) ** 0.5)
+    g = surface(n, extent, 1)[:, 1:].astype(np.int64)
+    n = len(g)
+    batch = {"coord": torch.from_numpy(((g + rng.random(g.shape)) * 0.02).astype(np.float32)).to(dev),
+             "grid_coord": torch.from_numpy(g).to(dev),
+             "feat": torch.from_numpy(rng.normal(size=(n, 9)).astype(np.float32)).to(dev),
+             "coord_feat": torch.from_numpy(rng.uniform(-1, 1, (n, 6)).astype(np.float32)).to(dev),
+             "offset": torch.tensor([n], device=dev)}
+    torch.manual_seed(0)
+    model = build_model(configs.SWIN3D_S3DIS_CFG).to(dev).eval()
+    with torch.no_grad():
+        for _ in range(2):
+            y = model(dict(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            y = model(dict(batch))
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(json.dumps({"model": "Swin3D-v1m1 (Swin3D-S, S3DIS config)", "points": n, "dtype": "float32",
+                      "ms_per_forward": round(ms, 2), "Mpoints_per_s": round(n / ms / 1e3, 3),
+                      "finite": bool(torch.isfinite(y).all().item())}))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
     dev = torch.device("cuda:0")
+    if len(sys.argv) > 2 and sys.argv[2] == "model":
+        return bench_model(n, dev)
     extent = int((n / 1.2) ** 0.5)
     coords = torch.from_numpy(surface(n, extent, 0)).to(dev)
     n = coords.shape[0]
