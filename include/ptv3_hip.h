@@ -477,6 +477,20 @@ int ptv3_swin_attn_fwd(const void* q, const void* k, const void* v, const float*
  * interpolation/interpolation_cuda_kernel.h) plus the stream. */
 int ptv3_knn_query(int m, int nsample, const float* xyz, const float* new_xyz, const int* offset,
                    const int* new_offset, int b, int* idx, float* dist2, void* stream);
+/* k nearest by a walk over the occupied cells of a uniform grid (cells of edge `cell`, the unit of xyz) instead of a
+ * scan of the scene: the k smallest by (distance, candidate index), each row ascending in that order.  Against
+ * ptv3_knn_query (= the reference's scan) every row holds the same distances and the same neighbours strictly closer than
+ * its k-th distance; which of several candidates AT the k-th distance is kept, and the order inside a group of equal
+ * distances, are by-products of the reference's heap and differ (lowest indices here).  nsample = 1: identical.
+ * qcell (m,4) int32: [scene, cx, cy, cz] of every query, cx = floor(x / cell) - min over the scene set, 0..65535;
+ * table / slots: ptv3_subm_build_table over the DISTINCT candidate cells (ncell,4); order (n) int64 + seg_start
+ * (ncell+1) int32: the candidates of cell c are order[seg_start[c] .. seg_start[c+1]) (ptv3_argsort_i64 +
+ * ptv3_pool_segments of the candidates' cell keys); offset (b) int32: the candidates' cumulative scene ends.  A query
+ * whose k-th neighbour is not settled within 8 shells (sparse surroundings, or a scene with fewer than nsample
+ * candidates, which pads with idx -1, dist2 1e10 as ptv3_knn_query does) is answered by a scan of its scene. */
+int ptv3_knn_query_cells(int m, int nsample, const float* xyz, const float* new_xyz, const int32_t* qcell,
+                         const void* table, int64_t slots, const int64_t* order, const int32_t* seg_start,
+                         const int* offset, float cell, int* idx, float* dist2, void* stream);
 int ptv3_grouping_forward(int m, int nsample, int c, const float* input, const int* idx, float* output,
                           void* stream);
 int ptv3_grouping_backward(int m, int nsample, int c, const float* grad_output, const int* idx,

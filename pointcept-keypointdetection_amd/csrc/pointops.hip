@@ -13,6 +13,7 @@
 // Reference: libs/pointops/src/knn_query/knn_query_cuda_kernel.cu:60-104,
 //            grouping/grouping_cuda_kernel.cu:5-25, interpolation/interpolation_cuda_kernel.cu:5-33.
 #include "common.h"
+#include "hashtable.h"
 #include <stdlib.h>
 #include "../../include/ptv3_hip.h"
 
@@ -148,6 +149,131 @@ knn_query_kernel(int m, int nsample, const float* __restrict__ xyz, const float*
   }
 }
 
+// ---- cell-grid kNN ----------------------------------------------------------------------------------------------
+// The k best of a query by the total order (distance, candidate index), found by walking the occupied cells of a
+// uniform grid in Chebyshev shells around the query's cell instead of scanning the whole scene.  A point in a cell at
+// Chebyshev distance >= r + 1 lies at least r * cell away from any point of the query's cell, so after shell r the
+// search stops once the k-th distance is below (r * cell)^2.  Against the reference's scan the DISTANCES of a row are
+// identical and so is every neighbour strictly closer than the k-th distance; among several candidates AT the k-th
+// distance the reference keeps whichever its heap did not happen to hold at the root when a closer candidate evicted
+// it, this search keeps the lowest indices, and rows ascend in (distance, index).  nsample = 1 leaves no such
+// freedom (strict `<` in index order keeps the first of equals in both): bit-identical.
+__device__ __forceinline__ bool pair_gt(float d1, int i1, float d2, int i2) { return d1 > d2 || (d1 == d2 && i1 > i2); }
+
+template <int KPL>
+__device__ __forceinline__ void pheap_sink_root(float (&hd)[KPL], int (&hi)[KPL], int size, float x, int xi, int lane) {
+  int root = 0;
+  for (;;) {
+    int child = 2 * root + 1;
+    if (child >= size) break;
+    float dc = heap_d<KPL>(hd, child);
+    int ic = heap_i<KPL>(hi, child);
+    if (child + 1 < size) {
+      const float dr = heap_d<KPL>(hd, child + 1);
+      const int ir = heap_i<KPL>(hi, child + 1);
+      if (pair_gt(dr, ir, dc, ic)) { ++child; dc = dr; ic = ir; }
+    }
+    if (pair_gt(x, xi, dc, ic)) break;
+    heap_set<KPL>(hd, hi, root, dc, ic, lane);
+    root = child;
+  }
+  heap_set<KPL>(hd, hi, root, x, xi, lane);
+}
+
+// offer candidate (d, i) of every lane with `has` to the wave's heap, in lane order
+template <int KPL>
+__device__ __forceinline__ void pheap_offer(float (&bd)[KPL], int (&bi)[KPL], int nsample, bool has, float d, int i,
+                                            float& tau_d, int& tau_i, int lane) {
+  unsigned long long hit = __ballot(has && pair_gt(tau_d, tau_i, d, i));
+  while (hit) {
+    const int src = __ffsll((long long)hit) - 1;
+    hit &= hit - 1;
+    const float dc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d), src));
+    const int ic = __builtin_amdgcn_readlane(i, src);
+    if (!pair_gt(tau_d, tau_i, dc, ic)) continue;   // against the root as it is NOW
+    pheap_sink_root<KPL>(bd, bi, nsample, dc, ic, lane);
+    tau_d = heap_d<KPL>(bd, 0);
+    tau_i = heap_i<KPL>(bi, 0);
+  }
+}
+
+constexpr int KNN_CELL_SHELLS = 8;   // shells walked before a query falls back to scanning its scene
+
+template <int KPL>
+__global__ void __launch_bounds__(256)
+knn_cells_kernel(int m, int nsample, const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                 const int* __restrict__ qcell, const unsigned long long* __restrict__ keys,
+                 const int* __restrict__ vals, unsigned long long mask, const long long* __restrict__ order,
+                 const int* __restrict__ seg_start, const int* __restrict__ offset, float cell,
+                 int* __restrict__ idx, float* __restrict__ dist2) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= m) return;  // whole wave leaves together
+  const float qx = new_xyz[3 * q], qy = new_xyz[3 * q + 1], qz = new_xyz[3 * q + 2];
+  const int cb = qcell[4 * q], cx = qcell[4 * q + 1], cy = qcell[4 * q + 2], cz = qcell[4 * q + 3];
+  float bd[KPL];
+  int bi[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) { bd[e] = 1e10f; bi[e] = 0x7fffffff; }   // sentinels lose every comparison
+  float tau_d = 1e10f;
+  int tau_i = 0x7fffffff;
+  bool done = false;
+  for (int r = 0; r <= KNN_CELL_SHELLS && !done; ++r) {
+    const int side = 2 * r + 1, ncube = side * side * side;
+    for (int base = 0; base < ncube; base += 64) {
+      const int t = base + lane;
+      int ci = -1;
+      if (t < ncube) {
+        const int dx = t / (side * side) - r, dy = (t / side) % side - r, dz = t % side - r;
+        const int ch = max(abs(dx), max(abs(dy), abs(dz)));
+        if (ch == r) ci = ht_find(keys, vals, mask, cb, cx + dx, cy + dy, cz + dz);
+      }
+      const int s0 = ci >= 0 ? seg_start[ci] : 0;
+      const int cnt = ci >= 0 ? seg_start[ci + 1] - s0 : 0;
+      for (int u = 0; __ballot(u < cnt); ++u) {
+        const bool has = u < cnt;
+        const int i = has ? (int)order[s0 + u] : 0x7fffffff;
+        float d = 3.0e38f;
+        if (has) d = dist2_ref(qx, qy, qz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+        pheap_offer<KPL>(bd, bi, nsample, has, d, i, tau_d, tau_i, lane);
+      }
+    }
+    // everything outside shell r is farther than r cells (a hair less: the cell of a point is a rounded division)
+    const float reach = (float)r * cell * 0.9999f;
+    done = tau_d < 1e10f && tau_d < reach * reach;
+  }
+  if (!done) {
+    // sparse neighbourhood (or a scene with fewer than nsample candidates): start over with a scan of the scene
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) { bd[e] = 1e10f; bi[e] = 0x7fffffff; }
+    tau_d = 1e10f;
+    tau_i = 0x7fffffff;
+    const int start = cb == 0 ? 0 : offset[cb - 1], end = offset[cb];
+    for (int base = start; base < end; base += 64) {
+      const int i = base + lane;
+      const bool has = i < end;
+      float d = 3.0e38f;
+      if (has) d = dist2_ref(qx, qy, qz, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+      pheap_offer<KPL>(bd, bi, nsample, has, d, has ? i : 0x7fffffff, tau_d, tau_i, lane);
+    }
+  }
+  // ascending (distance, index): repeatedly move the root behind the shrinking heap
+  for (int i = nsample - 1; i > 0; --i) {
+    const float xd = heap_d<KPL>(bd, i);
+    const int xi = heap_i<KPL>(bi, i);
+    heap_set<KPL>(bd, bi, i, heap_d<KPL>(bd, 0), heap_i<KPL>(bi, 0), lane);
+    pheap_sink_root<KPL>(bd, bi, i, xd, xi, lane);
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    const int p = lane + 64 * e;
+    if (p < nsample) {
+      idx[(int64_t)q * nsample + p] = bi[e] == 0x7fffffff ? -1 : bi[e];
+      dist2[(int64_t)q * nsample + p] = bd[e];
+    }
+  }
+}
+
 __global__ void grouping_forward_kernel(int64_t total, int nsample, int c, const float* __restrict__ input,
                                         const int* __restrict__ idx, float* __restrict__ output) {
   int64_t index = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -220,6 +346,26 @@ extern "C" int ptv3_knn_query(int m, int nsample, const float* xyz, const float*
     if (nq == 2) KNN_LAUNCH(2, 2); else KNN_LAUNCH(2, 1);
   }
 #undef KNN_LAUNCH
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_knn_query_cells(int m, int nsample, const float* xyz, const float* new_xyz, const int32_t* qcell,
+                                    const void* table, int64_t slots, const int64_t* order, const int32_t* seg_start,
+                                    const int* offset, float cell, int* idx, float* dist2, void* stream) {
+  PTV3_REQUIRE(nsample >= 1 && nsample <= 128, "knn_query_cells: nsample=%d outside [1,128]", nsample);
+  PTV3_REQUIRE(slots > 0 && (slots & (slots - 1)) == 0, "knn_query_cells: slots must be a power of two");
+  PTV3_REQUIRE(cell > 0.f, "knn_query_cells: cell %g", (double)cell);
+  if (m == 0) return PTV3_OK;
+  const unsigned long long* keys = (const unsigned long long*)table;
+  const int32_t* vals = (const int32_t*)((const char*)table + slots * 8);
+  dim3 grid((unsigned)cdiv(m, 4)), block(256);
+  if (nsample <= 64)
+    hipLaunchKernelGGL((knn_cells_kernel<1>), grid, block, 0, (hipStream_t)stream, m, nsample, xyz, new_xyz, qcell, keys,
+                       vals, (unsigned long long)(slots - 1), (const long long*)order, seg_start, offset, cell, idx, dist2);
+  else
+    hipLaunchKernelGGL((knn_cells_kernel<2>), grid, block, 0, (hipStream_t)stream, m, nsample, xyz, new_xyz, qcell, keys,
+                       vals, (unsigned long long)(slots - 1), (const long long*)order, seg_start, offset, cell, idx, dist2);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

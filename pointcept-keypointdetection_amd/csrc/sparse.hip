@@ -2,20 +2,10 @@
 // Replaces spconv's indice-pair generation (called lazily per indice_key by SubMConv3d in
 // point_transformer_v3m1_base.py:277-284,499-506 on the tensor built in structure.py:111-146).
 #include "common.h"
+#include "hashtable.h"
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
-
-constexpr uint64_t HT_EMPTY = ~0ull;
-
-__device__ __forceinline__ uint64_t site_key(int b, int x, int y, int z) {
-  return ((uint64_t)(uint32_t)b << 48) | ((uint64_t)(uint32_t)x << 32) | ((uint64_t)(uint32_t)y << 16) |
-         (uint64_t)(uint32_t)z;
-}
-__device__ __forceinline__ uint64_t mix64(uint64_t k) {
-  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-  return k;
-}
 
 __global__ void ht_insert_kernel(const int32_t* __restrict__ idx, int64_t n, unsigned long long* keys,
                                  int32_t* vals, uint64_t mask) {

@@ -12,9 +12,9 @@ the coordinate manager's jobs are done by this package's device primitives:
   BasicLayer window maps (swin3d_layers.py:715-824)             ptv3_swin_window_keys + sort + segments (swin3d_layers.window_attn_args)
   SelfAttnAIOFunction (:556-569)                                ptv3_swin_attn_fwd
   MinkowskiMaxPooling coordinates + GridCoordsDown (:180-231)   key sort + segments, segment mean, nearest-to-mean member
-  KNN k=16 + LayerNorm + Linear + MaxPool1d (:274-314)          LayerNorm + Linear per source voxel, then ptv3_knn_query and a
+  KNN k=16 + LayerNorm + Linear + MaxPool1d (:274-314)          LayerNorm + Linear per source voxel, then ptv3_knn_query_cells and a
                                                                 segment max over the 16 gathered rows (same result: both are per-row)
-  Upsample: Linear + 3-NN inverse-distance blend (:320-378)     ptv3_gemm + ptv3_knn_query + ptv3_interpolation_forward
+  Upsample: Linear + 3-NN inverse-distance blend (:320-378)     ptv3_gemm + ptv3_knn_query_cells + ptv3_interpolation_forward
   sp.slice(in_field) (:244)                                     row gather by the voxel id of every input point
 
 PARITY UNPINNED (oracle/swin3d.py header): MinkowskiEngine and microsoft/Swin3D are not in the reference tree.  Choices
@@ -152,7 +152,8 @@ class GridKNNDownsample(nn.Module):
         offset = _offsets(coords[:, 0], nb)
         # LayerNorm and Linear act row by row, so they run once per source voxel instead of once per gathered copy
         y = self.linear(self.norm(level.feat))
-        idx, _ = pointops.knn_query(self.k, level.xyz, level.offset, cfeat[:, 1:4].contiguous(), offset)
+        idx, _ = pointops.knn_query(self.k, level.xyz, level.offset, cfeat[:, 1:4].contiguous(), offset,
+                                     cell=float(level.stride))
         idx = torch.where(idx < 0, idx[:, :1], idx).long().reshape(-1).contiguous()
         starts = torch.arange(0, (m + 1) * self.k, self.k, device=idx.device, dtype=torch.int32)
         feat = ops.pool_max(y, idx, starts, m)
@@ -195,7 +196,7 @@ class Upsample(nn.Module):
 
     def forward(self, deep, shallow):
         carried = pointops.interpolation(deep.xyz, shallow.xyz, self.linear2(deep.feat).contiguous(), deep.offset,
-                                         shallow.offset, k=self.up_k)
+                                         shallow.offset, k=self.up_k, cell=float(deep.stride))
         shallow.feat = self.linear1(shallow.feat) + carried
         if self.attn:
             shallow, _ = self.block(shallow)

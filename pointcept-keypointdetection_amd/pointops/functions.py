@@ -22,17 +22,31 @@ def _i32(t):
     return t if t.dtype == torch.int32 and t.is_contiguous() else t.to(torch.int32).contiguous()
 
 
+# nsample = 1 over at least this many (query, candidate) pairs goes through the cell grid: the result is identical
+# (ptv3_knn_query_cells) and the label-mapping calls of the tester / evaluator (engines/test.py:939-945,
+# hooks/evaluator.py:569-575: 0.2-1M queries against ~100k voxels) stop costing a scan of the scene per query
+_CELL_GRID_PAIRS = 1 << 30
+
+
 @torch.no_grad()
-def knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None):
+def knn_query(nsample, xyz, offset, new_xyz=None, new_offset=None, cell=None):
     """k nearest candidates of every query inside its own scene (libs/pointops/functions/query.py:7-24).
     xyz (n, 3) candidates / offset (b) cumulative ends; new_xyz (m, 3) queries / new_offset (b); queries default to
     the candidates themselves.  Rows are ascending in distance; scenes with fewer than nsample candidates pad with
-    idx -1, dist sqrt(1e10)."""
+    idx -1, dist sqrt(1e10).
+    `cell` (not in the reference): edge of a uniform grid to search through instead of scanning the scene - same
+    distances, ties resolved by index (see ptv3_knn_query_cells); used by the Swin3D down / upsampling, whose
+    candidates are voxels of known size."""
     if new_xyz is None or new_offset is None:
         new_xyz, new_offset = xyz, offset
     if not (xyz.is_contiguous() and new_xyz.is_contiguous()):
         raise AssertionError("knn_query: xyz / new_xyz must be contiguous")
     m = new_xyz.shape[0]
+    from ptv3_hip import ops
+    if cell is not None or (nsample == 1 and m * xyz.shape[0] >= _CELL_GRID_PAIRS):
+        idx, dist2 = ops.knn_query_cells(nsample, xyz.float(), _i32(offset), new_xyz.float(), _i32(new_offset), cell)
+        return idx, dist2.sqrt_()
+    ops._check_offsets("knn_query", offset, xyz.shape[0], new_offset, m)   # the kernel trusts the scene ends
     idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
     dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
     _C.knn_query_cuda(m, nsample, xyz, new_xyz, _i32(offset), _i32(new_offset), idx, dist2)
@@ -106,12 +120,12 @@ class _KnnBlend(torch.autograd.Function):
         return acc, None, None
 
 
-def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3):
+def interpolation(xyz, new_xyz, feat, offset, new_offset, k=3, cell=None):
     """Features of `xyz` carried to `new_xyz` by normalised 1 / (distance + 1e-8) weights over the k nearest
-    (libs/pointops/functions/interpolation.py:8-25)."""
+    (libs/pointops/functions/interpolation.py:8-25).  `cell`: as in knn_query."""
     if not (xyz.is_contiguous() and new_xyz.is_contiguous() and feat.is_contiguous()):
         raise AssertionError("interpolation: xyz / new_xyz / feat must be contiguous")
-    idx, dist = knn_query(k, xyz, offset, new_xyz, new_offset)
+    idx, dist = knn_query(k, xyz, offset, new_xyz, new_offset, cell=cell)
     w = torch.reciprocal(dist + 1e-8)
     w = (w / w.sum(dim=1, keepdim=True)).contiguous()
     return _KnnBlend.apply(feat, idx, w)

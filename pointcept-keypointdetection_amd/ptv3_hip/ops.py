@@ -743,10 +743,73 @@ def knn_query(nsample, xyz, offset, new_xyz, new_offset):
     _chk(offset, "offset", torch.int32, 1)
     _chk(new_offset, "new_offset", torch.int32, 1)
     m = new_xyz.shape[0]
+    _check_offsets("knn_query", offset, xyz.shape[0], new_offset, m)
     idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
     dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
     lib.check(lib.ptv3_knn_query(m, int(nsample), _p(xyz), _p(new_xyz), _p(offset), _p(new_offset),
                                  offset.shape[0], _p(idx), _p(dist2), _stream()), "ptv3_knn_query")
+    return idx, dist2
+
+
+def _scene_ids(offset, n):
+    counts = torch.diff(offset.long(), prepend=offset.new_zeros(1).long())
+    return torch.repeat_interleave(torch.arange(offset.shape[0], device=offset.device), counts, output_size=n)
+
+
+def _check_offsets(what, offset, n, new_offset, m):
+    """The kernels trust the scene ends: a wrong last entry walks past the coordinate arrays."""
+    ends = torch.stack([offset[-1], new_offset[-1]]).tolist()
+    if ends != [n, m] or offset.shape != new_offset.shape:
+        raise ValueError(f"{what}: offsets end at {ends} for {n} candidates / {m} queries "
+                         f"({offset.shape[0]} / {new_offset.shape[0]} scenes)")
+
+
+def knn_query_cells(nsample, xyz, offset, new_xyz, new_offset, cell=None):
+    """ptv3_knn_query_cells: the neighbours of knn_query by a walk over a uniform grid of edge `cell` (same unit as xyz;
+    default: an estimate of the nsample-th neighbour distance from the candidates' bounding box, so that one or two
+    shells of cells settle a query).  Rows ascend in (distance, index).  Host syncs: offsets check + grid extent, number
+    of occupied cells."""
+    _chk(xyz, "xyz", torch.float32, 2)
+    _chk(new_xyz, "new_xyz", torch.float32, 2)
+    _chk(offset, "offset", torch.int32, 1)
+    _chk(new_offset, "new_offset", torch.int32, 1)
+    n, m = xyz.shape[0], new_xyz.shape[0]
+    dev = xyz.device
+    idx = torch.full((m, nsample), -1, dtype=torch.int32, device=dev)
+    dist2 = torch.full((m, nsample), 1e10, dtype=torch.float32, device=dev)
+    if m == 0 or n == 0:
+        return idx, dist2
+    _check_offsets("knn_query_cells", offset, n, new_offset, m)
+    lo_f = torch.minimum(xyz.amin(0), new_xyz.amin(0))
+    hi_f = torch.maximum(xyz.amax(0), new_xyz.amax(0))
+    if cell is None:
+        # distance to the nsample-th neighbour if the candidates fill their bounding box (r_vol) or lie on a sheet across
+        # its largest face (r_surf): a sheet in a thick box makes r_vol too large (cells hold more candidates than
+        # needed, still correct), a filled box makes r_surf too small (many shells), hence the clamp
+        ext = torch.sort((xyz.amax(0) - xyz.amin(0)).clamp_min(1e-12)).values.tolist()
+        r_surf = (nsample * ext[1] * ext[2] / (3.14159 * n)) ** 0.5
+        r_vol = (3.0 * nsample * ext[0] * ext[1] * ext[2] / (4 * 3.14159 * n)) ** (1.0 / 3.0)
+        cell = max(r_surf, min(r_vol, 4.0 * r_surf), 1e-9)
+    cell = float(cell)
+    cell_t = torch.full((), cell, dtype=torch.float32, device=dev)
+    base = torch.floor(lo_f / cell_t)
+    csrc = (torch.floor(xyz / cell_t) - base).int()
+    cq = (torch.floor(new_xyz / cell_t) - base).int()
+    extent = int(torch.maximum(csrc.amax(), cq.amax()))
+    if extent >= 65536:
+        raise ValueError(f"knn_query_cells: {extent + 1} cells of edge {cell} along one axis (limit 65536): use a larger cell")
+    src_cells = torch.cat([_scene_ids(offset, n).int().unsqueeze(1), csrc], dim=1).contiguous()
+    q_cells = torch.cat([_scene_ids(new_offset, m).int().unsqueeze(1), cq], dim=1).contiguous()
+    c = src_cells.long()
+    key = (((c[:, 0] << 16 | c[:, 1]) << 16 | c[:, 2]) << 16 | c[:, 3]).contiguous()
+    order, _, seg_start, ncell = voxel_unique(key)
+    uniq = src_cells[order[seg_start[:-1].long()]].contiguous()
+    slots = lib.ptv3_subm_table_slots(ncell)
+    table = torch.empty(slots * 12, dtype=torch.uint8, device=dev)
+    lib.check(lib.ptv3_subm_build_table(_p(uniq), ncell, _p(table), slots, _stream()), "ptv3_subm_build_table")
+    lib.check(lib.ptv3_knn_query_cells(m, int(nsample), _p(xyz), _p(new_xyz), _p(q_cells), _p(table), slots, _p(order),
+                                       _p(seg_start), _p(offset), cell, _p(idx), _p(dist2), _stream()),
+              "ptv3_knn_query_cells")
     return idx, dist2
 
 

@@ -136,3 +136,77 @@ def test_interpolation_forward_backward_vs_c_oracle(dev):
     out2 = pointops.interpolation2(torch.from_numpy(xyz).to(dev), torch.from_numpy(new_xyz).to(dev), f.detach(),
                                    torch.from_numpy(offset).to(dev), torch.from_numpy(new_offset).to(dev), k)
     assert torch.equal(out2, out.detach())
+
+
+def _sorted_pairs(idx, d2):
+    """rows as (distance, index) pairs in ascending pair order - the order knn_query_cells writes."""
+    out_i, out_d = np.empty_like(idx), np.empty_like(d2)
+    for r in range(idx.shape[0]):
+        o = np.lexsort((idx[r], d2[r]))
+        out_i[r], out_d[r] = idx[r][o], d2[r][o]
+    return out_i, out_d
+
+
+@pytest.mark.parametrize("nsample,kind", [(1, "grid"), (3, "grid"), (16, "grid"), (16, "float"), (3, "float"),
+                                          (70, "float")])
+def test_knn_query_cells_against_the_reference_scan(dev, nsample, kind):
+    """ptv3_knn_query_cells against the restated reference scan.  Every row holds the same DISTANCES bit for bit; the
+    neighbours strictly closer than the row's k-th distance are the same set; a neighbour AT the k-th distance may be a
+    different member of that tie group (which of several equidistant candidates survives in the reference depends on
+    where its heap happened to hold them when a closer candidate evicted the root) and the order inside any tie group
+    is ascending index instead of the heap's by-product.  nsample = 1 has no such freedom: bit-identical.
+    Gridded coordinates make ties (also at the k-th distance) the common case; three scenes, one of them smaller than
+    nsample (padding with -1 / 1e10), queries far outside the candidates (fallback scan)."""
+    from ptv3_hip import ops
+    from oracle import pointops as OP
+    rng = np.random.default_rng(7 + nsample)
+    sizes = [4000, 12, 2500]
+    qsizes = [1500, 9, 800]
+    if kind == "grid":
+        xyz = np.concatenate([_grid_scene(rng, s, 22) for s in sizes])
+        new_xyz = np.concatenate([_grid_scene(rng, s, 26) for s in qsizes])
+        cell = 0.05
+    else:
+        xyz = np.concatenate([rng.normal(size=(s, 3)) * [3, 3, 0.2] for s in sizes]).astype(np.float32)
+        new_xyz = np.concatenate([rng.normal(size=(s, 3)) * [3, 3, 0.2] for s in qsizes]).astype(np.float32)
+        new_xyz[:5] += 40.0                      # outliers: nothing within the shells
+        cell = None
+    offset = np.cumsum(sizes).astype(np.int32)
+    new_offset = np.cumsum(qsizes).astype(np.int32)
+    want_i, want_d = OP.knn_query(nsample, xyz, offset, new_xyz, new_offset)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    got_i, got_d = ops.knn_query_cells(nsample, t(xyz), t(offset), t(new_xyz), t(new_offset), cell)
+    got_i, got_d = got_i.cpu().numpy(), got_d.cpu().numpy()
+    if nsample == 1:
+        assert np.array_equal(got_i, want_i) and np.array_equal(got_d, want_d)
+    si, sd = _sorted_pairs(got_i, got_d)
+    assert np.array_equal(si, got_i) and np.array_equal(sd, got_d)          # rows ascend in (distance, index)
+    wi, wd = _sorted_pairs(want_i, want_d)
+    assert np.array_equal(got_d, wd)                                        # the same distances, bit for bit
+    start = np.concatenate([[0], offset[:-1]])
+    scene = np.repeat(np.arange(3), qsizes)
+    for r in range(len(new_xyz)):
+        real = got_i[r] >= 0
+        assert real.sum() == min(nsample, sizes[scene[r]]) and (got_d[r][~real] == 1e10).all()
+        ids = got_i[r][real]
+        assert len(set(ids.tolist())) == len(ids)
+        assert (ids >= start[scene[r]]).all() and (ids < offset[scene[r]]).all()
+        d = xyz[ids] - new_xyz[r]
+        assert np.array_equal((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2], got_d[r][real])
+        inside = got_d[r] < got_d[r][real][-1]
+        assert set(got_i[r][inside].tolist()) == set(wi[r][wd[r] < got_d[r][real][-1]].tolist())
+
+
+def test_knn_rejects_offsets_that_do_not_end_at_the_row_counts(dev):
+    """The kernels trust the scene ends; a last entry beyond the arrays would read past them."""
+    import pointops
+    from ptv3_hip import ops
+    xyz = torch.rand(100, 3, device=dev)
+    good = torch.tensor([100], dtype=torch.int32, device=dev)
+    bad = torch.tensor([1000], dtype=torch.int32, device=dev)
+    for fn in (lambda: pointops.knn_query(2, xyz, good, xyz, bad), lambda: ops.knn_query(2, xyz, bad, xyz, good),
+               lambda: ops.knn_query_cells(2, xyz, good, xyz, bad)):
+        with pytest.raises(ValueError, match="offsets end at"):
+            fn()
+    idx, _ = pointops.knn_query(1, xyz, good)
+    assert torch.equal(idx[:, 0].cpu(), torch.arange(100, dtype=torch.int32))
