@@ -333,8 +333,9 @@ size_t ptv3_col_reduce_workspace_bytes(int64_t m, int c);
 int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, int mode, float* out,
                     int64_t m, int c, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* LayerNorm backward (statistics recomputed from x): dx (m, c) dtype, dgamma_dbeta (2, c) fp32.
- * workspace: ptv3_col_reduce_workspace_bytes(m, c). */
-int ptv3_layernorm_bwd(const void* x, const void* dy, const float* gamma, float eps, void* dx,
+ * add (m, c) dtype or NULL: dx = add + (input gradient) - the gradient arriving over the residual connection around the
+ * normalised branch (Block.forward, :318-338), folded into the store.  workspace: ptv3_col_reduce_workspace_bytes(m, c). */
+int ptv3_layernorm_bwd(const void* x, const void* dy, const void* add, const float* gamma, float eps, void* dx,
                        float* dgamma_dbeta, int64_t m, int c, int dtype, void* workspace,
                        size_t workspace_bytes, void* stream);
 /* dx = dy * act'(x * scale[c] + shift[c])  (scale = shift = NULL: act'(x)); act = PTV3_ACT_* */
@@ -391,11 +392,16 @@ int ptv3_adamw_fill_shadow(void* entry_host, void* shadow, void* shadow_t, int r
  * ptv3_adamw_step (torch.optim.AdamW keeps state["step"] per parameter: a parameter that first receives a gradient
  * later, or a resumed checkpoint, engines/hooks/misc.py:269); its bias corrections use step - step_lag. */
 int ptv3_adamw_fill_step_lag(void* entry_host, int64_t step_lag);
+/* grads_host (ntensors host array of device pointers) or NULL: this step's gradient of every table entry, overriding the
+ * address stored in the table.  torch's autograd leaves a new gradient tensor on each parameter after
+ * zero_grad(set_to_none=True) (no zero fill, no accumulate-add per parameter); the addresses travel as kernel arguments,
+ * 256 tensors per launch, so the table is neither rebuilt nor re-uploaded.  first_block_host (ntensors): the
+ * first_block given to ptv3_adamw_fill_entry for every entry (required with grads_host). */
 int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
                     const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
-                    float grad_scale, void* stream);
+                    float grad_scale, const int32_t* first_block_host, const void* const* grads_host, void* stream);
 int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws, float* out,
-                     void* stream);
+                     const int32_t* first_block_host, const void* const* grads_host, void* stream);
 
 /* ---- GridSample (the step before the model) -----------------------------------------------------------
  * Front half of pointcept/datasets/transform.py:848-860 for one cloud: grid_coord = floor(coord / grid_size)

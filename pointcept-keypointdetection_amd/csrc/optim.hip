@@ -21,20 +21,29 @@ struct AdamWTensor {
 };
 
 struct AdamWGroups { float lr[8], wd[8]; };
+// gradient addresses of up to 256 consecutive table entries, handed over as a kernel argument: autograd leaves a NEW
+// gradient tensor on every parameter each step (after zero_grad(set_to_none=True)), and a by-value argument needs neither
+// a table rebuild nor a host-to-device copy that the next step's host code could race with
+constexpr int ADAMW_PTRS = 256;
+struct AdamWGrads { const float* g[ADAMW_PTRS]; };
 
 constexpr int ADAMW_CHUNK = 4096;  // elements per block
 
-__global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restrict__ tab, int ntensors,
-                                                     AdamWGroups grp, float beta1, float beta2, float eps,
-                                                     float bc1, float rsqrt_bc2, float grad_scale, float step_no) {
-  // find the tensor owning this block
-  int lo = 0, hi = ntensors - 1;
+template <bool PTRS>
+__global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restrict__ tab, int tensor_lo, int tensor_hi,
+                                                     int block_base, AdamWGrads gp, AdamWGroups grp, float beta1,
+                                                     float beta2, float eps, float bc1, float rsqrt_bc2,
+                                                     float grad_scale, float step_no) {
+  // find the tensor owning this block (entries tensor_lo .. tensor_hi of the table)
+  const int blk = block_base + (int)blockIdx.x;
+  int lo = tensor_lo, hi = tensor_hi;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (tab[mid].first_block <= blk) lo = mid; else hi = mid - 1;
   }
-  const AdamWTensor t = tab[lo];
-  const int64_t base = (int64_t)(blockIdx.x - t.first_block) * ADAMW_CHUNK;
+  AdamWTensor t = tab[lo];
+  if (PTRS) t.g = gp.g[lo - tensor_lo];
+  const int64_t base = (int64_t)(blk - t.first_block) * ADAMW_CHUNK;
   const float lr = grp.lr[t.group], wd = grp.wd[t.group];
   if (t.step_lag != 0) {  // this tensor's own step count (block-uniform branch)
     const float own = step_no - (float)t.step_lag;
@@ -71,16 +80,19 @@ __global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restric
 }
 
 // sum of squares of every gradient (for clip_grad_norm_): per-block partials -> one value, deterministic
-__global__ void __launch_bounds__(256) grad_sq_kernel(const AdamWTensor* __restrict__ tab, int ntensors,
-                                                       float* __restrict__ partial) {
+template <bool PTRS>
+__global__ void __launch_bounds__(256) grad_sq_kernel(const AdamWTensor* __restrict__ tab, int tensor_lo, int tensor_hi,
+                                                       int block_base, AdamWGrads gp, float* __restrict__ partial) {
   __shared__ float red[256];
-  int lo = 0, hi = ntensors - 1;
+  const int blk = block_base + (int)blockIdx.x;
+  int lo = tensor_lo, hi = tensor_hi;
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
-    if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    if (tab[mid].first_block <= blk) lo = mid; else hi = mid - 1;
   }
-  const AdamWTensor t = tab[lo];
-  const int64_t base = (int64_t)(blockIdx.x - t.first_block) * ADAMW_CHUNK;
+  AdamWTensor t = tab[lo];
+  if (PTRS) t.g = gp.g[lo - tensor_lo];
+  const int64_t base = (int64_t)(blk - t.first_block) * ADAMW_CHUNK;
   float s = 0.f;
   for (int64_t j = base + threadIdx.x; j < base + ADAMW_CHUNK && j < t.numel; j += 256) s += t.g[j] * t.g[j];
   red[threadIdx.x] = s;
@@ -89,7 +101,7 @@ __global__ void __launch_bounds__(256) grad_sq_kernel(const AdamWTensor* __restr
     if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) partial[blk] = red[0];
 }
 
 __global__ void __launch_bounds__(256) sum_partials_kernel(const float* __restrict__ partial, int n, float* out) {
@@ -142,9 +154,33 @@ extern "C" int ptv3_adamw_fill_shadow(void* entry_host, void* shadow, void* shad
   return PTV3_OK;
 }
 
+// launches over the table in runs of <= ADAMW_PTRS tensors when gradient addresses come from the host
+template <typename F>
+static int adamw_runs(int ntensors, int total_blocks, const int32_t* first_block_host, const void* const* grads_host,
+                      F&& launch) {
+  if (!grads_host) {
+    AdamWGrads none{};
+    launch(false, 0, ntensors - 1, 0, total_blocks, none);
+    return PTV3_OK;
+  }
+  PTV3_REQUIRE(first_block_host != nullptr, "adamw: gradient pointers need the tensors' first blocks");
+  for (int t0 = 0; t0 < ntensors; t0 += ADAMW_PTRS) {
+    const int t1 = t0 + ADAMW_PTRS < ntensors ? t0 + ADAMW_PTRS : ntensors;
+    AdamWGrads gp{};
+    for (int i = t0; i < t1; ++i) {
+      PTV3_REQUIRE(grads_host[i] != nullptr, "adamw: gradient %d is NULL", i);
+      gp.g[i - t0] = (const float*)grads_host[i];
+    }
+    const int b0 = first_block_host[t0], b1 = t1 < ntensors ? first_block_host[t1] : total_blocks;
+    if (b1 > b0) launch(true, t0, t1 - 1, b0, b1 - b0, gp);
+  }
+  return PTV3_OK;
+}
+
 extern "C" int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
                                const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
-                               float grad_scale, void* stream) {
+                               float grad_scale, const int32_t* first_block_host, const void* const* grads_host,
+                               void* stream) {
   PTV3_REQUIRE(ngroups >= 1 && ngroups <= 8, "adamw: ngroups %d outside [1,8]", ngroups);
   PTV3_REQUIRE(step >= 1, "adamw: step must be >= 1");
   if (ntensors == 0 || total_blocks == 0) return PTV3_OK;
@@ -152,22 +188,40 @@ extern "C" int ptv3_adamw_step(const void* table_dev, int ntensors, int total_bl
   for (int i = 0; i < 8; ++i) { grp.lr[i] = i < ngroups ? lr_host[i] : 0.f; grp.wd[i] = i < ngroups ? wd_host[i] : 0.f; }
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const AdamWTensor*)table_dev, ntensors, grp, beta1, beta2, eps, (float)bc1,
-                     (float)(1.0 / sqrt(bc2)), grad_scale, (float)step);
+  const AdamWTensor* tab = (const AdamWTensor*)table_dev;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = adamw_runs(ntensors, total_blocks, first_block_host, grads_host,
+                            [&](bool ptrs, int lo, int hi, int b0, int nb, const AdamWGrads& gp) {
+    if (ptrs)
+      hipLaunchKernelGGL(adamw_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, tab, lo, hi, b0, gp, grp, beta1, beta2,
+                         eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, (float)step);
+    else
+      hipLaunchKernelGGL(adamw_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, tab, lo, hi, b0, gp, grp, beta1, beta2,
+                         eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, (float)step);
+  });
+  if (rc != PTV3_OK) return rc;
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }
 
 extern "C" int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws,
-                                float* out, void* stream) {
+                                float* out, const int32_t* first_block_host, const void* const* grads_host,
+                                void* stream) {
+  hipStream_t s = (hipStream_t)stream;
   if (ntensors == 0 || total_blocks == 0) {
-    if (hipMemsetAsync(out, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return PTV3_ERR_LAUNCH;
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
     return PTV3_OK;
   }
-  hipLaunchKernelGGL(grad_sq_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const AdamWTensor*)table_dev, ntensors, partial_ws);
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial_ws, total_blocks, out);
+  const AdamWTensor* tab = (const AdamWTensor*)table_dev;
+  const int rc = adamw_runs(ntensors, total_blocks, first_block_host, grads_host,
+                            [&](bool ptrs, int lo, int hi, int b0, int nb, const AdamWGrads& gp) {
+    if (ptrs)
+      hipLaunchKernelGGL(grad_sq_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, tab, lo, hi, b0, gp, partial_ws);
+    else
+      hipLaunchKernelGGL(grad_sq_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, tab, lo, hi, b0, gp, partial_ws);
+  });
+  if (rc != PTV3_OK) return rc;
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, s, partial_ws, total_blocks, out);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

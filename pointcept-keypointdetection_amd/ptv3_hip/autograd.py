@@ -402,15 +402,13 @@ class BlockFn(Function):
         dh, dW_fc2, db_fc2 = _lin_bwd(dm, h, w_fc2, gran)
         dh0 = ops.act_bwd(dh, h0, ops.ACT_GELU)
         dt5, dW_fc1, db_fc1 = _lin_bwd(dh0, t5, w_fc1, gran)
-        dx, dg2, db2 = ops.layernorm_bwd(f2, dt5, f32(n2_g), eps)
-        df2 = dout + dx
+        df2, dg2, db2 = ops.layernorm_bwd(f2, dt5, f32(n2_g), eps, add=dout)
         # ---- attention branch
         dp = df2 if mask1 is None else df2 * mask1
         da, dW_proj, db_proj = _lin_bwd(dp, a, w_proj, gran)
         dqkv = ops.window_attention_bwd(qkv, a, da.contiguous(), wo, wi, heads, patch, scale, cu)
         dt3, dW_qkv, db_qkv = _lin_bwd(dqkv, t3, w_qkv, gran)
-        dx, dg1, db1 = ops.layernorm_bwd(f1, dt3, f32(n1_g), eps)
-        df1 = df2 + dx
+        df1, dg1, db1 = ops.layernorm_bwd(f1, dt3, f32(n1_g), eps, add=df2)
         # ---- xCPE branch
         dc2, dg0, db0 = ops.layernorm_bwd(c2, df1, f32(ln0_g), eps)
         dc1, dW_lin, db_lin = _lin_bwd(dc2, c1, w_lin, gran)
@@ -419,10 +417,11 @@ class BlockFn(Function):
         wt = w_conv[1]
         if wt is None:
             wt = w_conv[0].view(cout, kvol, cin).flip(1).permute(2, 1, 0).reshape(cin, -1).contiguous()
-        dxin = ops.gemm(_pad_cols(dc1, gran), wt, nbr=nbr, kvol=kvol, row_order=row_order)
+        # same: the conv read `feat` itself, its input gradient lands on df1 in the GEMM epilogue
+        dxin = ops.gemm(_pad_cols(dc1, gran), wt, nbr=nbr, kvol=kvol, row_order=row_order, res=df1 if same else None)
         dW_conv = ops.gemm_tn(dc1, xin, nbr, kvol).view(conv_w.shape)
         db_conv = ops.col_reduce(dc1)
-        dfeat = df1 + dxin if same else df1
+        dfeat = dxin if same else df1
         c = lambda t: t.to(pd)  # noqa: E731
         return (dfeat, None if same else dxin, c(dW_conv), c(db_conv), c(dW_lin), c(db_lin), c(dg0), c(db0), c(dg1),
                 c(db1), c(dW_qkv), c(db_qkv), c(dW_proj), c(db_proj), c(dg2), c(db2), c(dW_fc1), c(db_fc1), c(dW_fc2),

@@ -58,7 +58,7 @@ SIGNATURES = {
     "ptv3_gemm_tn": (c_int, [P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "ptv3_col_reduce_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "ptv3_col_reduce": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
-    "ptv3_layernorm_bwd": (c_int, [P, P, P, c_float, P, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "ptv3_layernorm_bwd": (c_int, [P, P, P, P, c_float, P, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "ptv3_act_bwd": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, c_int, P]),
     "ptv3_affine2": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "ptv3_pool_max_bwd": (c_int, [P, P, P, P, c_int64, c_int, P, c_int, P]),
@@ -76,8 +76,8 @@ SIGNATURES = {
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
     "ptv3_adamw_fill_shadow": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "ptv3_adamw_fill_step_lag": (c_int, [P, c_int64]),
-    "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P]),
-    "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P]),
+    "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P, P, P]),
+    "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "ptv3_grid_hash": (c_int, [P, c_int64, c_double, c_int, P, P, P, P]),
     "ptv3_keypoint_aggregate": (c_int, [P, P, P, c_int, c_int, P, P, c_int, c_float, P, P, P]),
     "ptv3_profile_enable": (c_int, [c_int]),

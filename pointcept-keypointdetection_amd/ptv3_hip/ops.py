@@ -501,17 +501,20 @@ def col_reduce(a, b=None, mu=None, rs=None, mode=0):
     return out[0] if mode == 0 else out
 
 
-def layernorm_bwd(x, dy, gamma, eps):
-    """-> dx (m, c), dgamma (c), dbeta (c)."""
+def layernorm_bwd(x, dy, gamma, eps, add=None):
+    """-> dx (m, c) [+ add], dgamma (c), dbeta (c)."""
     _chk(x, "x", _F, 2)
     _chk(dy, "dy", x.dtype, 2)
+    _chk(add, "add", x.dtype, 2)
+    if add is not None and add.shape != x.shape:
+        raise RuntimeError("layernorm_bwd: add must have the shape of x")
     _chk(gamma, "gamma", torch.float32, 1)
     m, c = x.shape
     dx = torch.empty_like(x)
     dgb = torch.empty((2, c), dtype=torch.float32, device=x.device)
     nb = lib.ptv3_col_reduce_workspace_bytes(m, c)
     ws = _ws(nb, x.device)
-    lib.check(lib.ptv3_layernorm_bwd(_p(x), _p(dy), _p(gamma), float(eps), _p(dx), _p(dgb), m, c, _dt(x), _p(ws), nb,
+    lib.check(lib.ptv3_layernorm_bwd(_p(x), _p(dy), _p(add), _p(gamma), float(eps), _p(dx), _p(dgb), m, c, _dt(x), _p(ws), nb,
                                      _stream()), "ptv3_layernorm_bwd")
     return dx, dgb[0], dgb[1]
 

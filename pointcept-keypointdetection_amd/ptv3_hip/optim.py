@@ -86,8 +86,11 @@ class FusedAdamW(torch.optim.Optimizer):
     def _build(self):
         ent = self._entries()
         shadows = [self._shadow(p) for p, _, _ in ent]
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), gi, 0 if sh is None else sh["nat"].data_ptr())
+        # gradient addresses are NOT part of the key: they change every step after zero_grad(set_to_none=True) and
+        # travel to the kernel as launch arguments (self._grad_ptrs)
+        key = tuple((p.data_ptr(), gi, 0 if sh is None else sh["nat"].data_ptr())
                     for (p, _, gi), sh in zip(ent, shadows))
+        self._grad_ptrs = (ctypes.c_void_p * max(1, len(ent)))(*[p.grad.data_ptr() for p, _, _ in ent])
         if key == self._key:
             return
         self._sync_steps()   # tensors leaving the table keep their own count in state["step"]
@@ -98,7 +101,9 @@ class FusedAdamW(torch.optim.Optimizer):
         host = ctypes.create_string_buffer(max(1, esz * len(ent)))
         base = ctypes.addressof(host)
         blocks = 0
+        first = []
         for i, (p, st, gi) in enumerate(ent):
+            first.append(blocks)
             lib.check(lib.ptv3_adamw_fill_entry(base + i * esz, p.data_ptr(), p.grad.data_ptr(),
                                                 st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel(), gi,
                                                 blocks), "ptv3_adamw_fill_entry")
@@ -116,6 +121,7 @@ class FusedAdamW(torch.optim.Optimizer):
         dev = ent[0][0].device if ent else torch.device("cuda")
         self._table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
         self._partial = torch.empty(max(blocks, 1), dtype=torch.float32, device=dev)
+        self._first_blocks = (ctypes.c_int32 * max(1, len(first)))(*first)
         self._nt, self._nb, self._key, self._active = len(ent), blocks, key, active
 
     def _sync_steps(self):
@@ -139,9 +145,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._key, self._active = None, []   # moments are new tensors: rebuild the device table, re-derive the lags
 
     @torch.no_grad()
-    def zero_grad(self, set_to_none=False):
-        """Default keeps the gradient tensors (stable addresses: the device table is built once) and zeroes
-        them with multi-tensor fills instead of one launch per parameter."""
+    def zero_grad(self, set_to_none=True):
+        """Default drops the gradient tensors (torch's own default): the next backward then hands every parameter a
+        fresh tensor - no zero fill and no accumulate-add launch per parameter (~450 + ~130 launches of the fork
+        model's step) - and step() passes the new addresses to the kernel as launch arguments.  set_to_none=False keeps
+        the tensors and zeroes them with multi-tensor fills."""
         if set_to_none:
             return super().zero_grad(set_to_none=True)
         grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
@@ -161,8 +169,8 @@ class FusedAdamW(torch.optim.Optimizer):
         wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
         b1, b2 = self.param_groups[0]["betas"]
         lib.check(lib.ptv3_adamw_step(self._table.data_ptr(), self._nt, self._nb, lr, wd, ng, float(b1), float(b2),
-                                      float(self.param_groups[0]["eps"]), self._steps, float(grad_scale), _stream()),
-                  "ptv3_adamw_step")
+                                      float(self.param_groups[0]["eps"]), self._steps, float(grad_scale),
+                                      self._first_blocks, self._grad_ptrs, _stream()), "ptv3_adamw_step")
         # The kernel wrote the parameters through raw pointers: tell torch.  Every eval-side cache (folded BatchNorm,
         # cast / permuted weights, the executor's packed table) is keyed on (data_ptr, _version); without the bump an
         # evaluation between two training epochs would keep running on the weights of the first one.
@@ -180,5 +188,6 @@ class FusedAdamW(torch.optim.Optimizer):
         self._build()
         out = torch.empty(1, dtype=torch.float32, device=self._table.device)
         lib.check(lib.ptv3_grad_sqnorm(self._table.data_ptr(), self._nt, self._nb, self._partial.data_ptr(),
-                                       out.data_ptr(), _stream()), "ptv3_grad_sqnorm")
+                                       out.data_ptr(), self._first_blocks, self._grad_ptrs, _stream()),
+                  "ptv3_grad_sqnorm")
         return out.sqrt_()[0]

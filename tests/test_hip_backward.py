@@ -98,6 +98,30 @@ def test_layernorm_backward(dev, m, c):
     _close(bd.grad, br.grad, what="dbeta")
 
 
+@pytest.mark.parametrize("m,c,dtype", [(100003, 32, torch.float32), (4097, 64, torch.bfloat16), (1001, 256, torch.float32),
+                                       (515, 48, torch.float32), (130, 512, torch.bfloat16)])
+def test_layernorm_backward_with_residual_gradient(dev, m, c, dtype):
+    """ptv3_layernorm_bwd(add=...): dx = add + d/dx LayerNorm, the residual connection's gradient folded into the
+    store (Block backward); packed-row kernel (c a power of two in 32..256) and the one-wave-per-row kernel."""
+    from ptv3_hip import ops
+    g = torch.Generator().manual_seed(c + m)
+    x = (torch.randn(m, c, generator=g) * 2 + 0.5).to(dtype)
+    gm, dy, add = torch.randn(c, generator=g), torch.randn(m, c, generator=g).to(dtype), torch.randn(m, c, generator=g).to(dtype)
+    xr = _leaf(x.float())
+    gr = _leaf(gm)
+    br = _leaf(torch.zeros(c))
+    F.layer_norm(xr, (c,), gr, br, 1e-5).backward(dy.float())
+    dx, dg, db = ops.layernorm_bwd(x.to(dev), dy.to(dev), gm.to(dev), 1e-5, add=add.to(dev))
+    plain, dg0, db0 = ops.layernorm_bwd(x.to(dev), dy.to(dev), gm.to(dev), 1e-5)
+    want = add.float() + xr.grad
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -7
+    assert (dx.float().cpu() - want).abs().max() <= tol * max(1.0, want.abs().max())
+    assert (plain.float().cpu() - xr.grad).abs().max() <= tol * max(1.0, xr.grad.abs().max())
+    for got, ref in ((dg, gr.grad), (db, br.grad)):
+        assert (got.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max()) * (1 if dtype == torch.float32 else 1)
+    assert torch.equal(dg, dg0) and torch.equal(db, db0)
+
+
 @pytest.mark.parametrize("training", [True, False])
 @pytest.mark.parametrize("act", ["none", "gelu", "relu"])
 def test_batchnorm_act_backward(dev, training, act):
