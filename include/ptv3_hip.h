@@ -320,10 +320,12 @@ int ptv3_forward(const ptv3_model_desc* desc, const void* const* params, int num
  * dw (cout, kvol*cin) fp32 = dy^T (m, cout) . gather(x (m, cin) through nbr (m, kvol))   [kvol=1: nbr NULL]
  *   = weight gradient of nn.Linear (point_transformer_v3m1_base.py:188,219,232-244) and of SubMConv3d
  *   (:277-284, 499-506) in the layout of ptv3_gemm's w.  Input gradients reuse ptv3_gemm itself: linear with
- *   w^T; sparse conv with w'[c][t][o] = w[o][kvol-1-t][c] (submanifold neighbour maps are symmetric). */
+ *   w^T; sparse conv with w'[c][t][o] = w[o][kvol-1-t][c] (submanifold neighbour maps are symmetric).
+ * dbias (cout) fp32 or NULL: the bias gradient sum_i dy[i][:] from the same pass (the staging of dy sees every
+ *   element once; a separate column reduction would read dy again and cost two more launches per layer). */
 size_t ptv3_gemm_tn_workspace_bytes(int64_t m, int cout, int cin, int kvol);
-int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, int64_t m, int cout, int cin,
-                 int kvol, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, float* dbias, int64_t m, int cout,
+                 int cin, int kvol, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* column reductions over the m rows of a (and b), out fp32:
  *   mode 0: out[c]       = sum a                          (bias gradients)
  *   mode 1: out[2][c]    = sum a, sum a*a                 (BatchNorm1d batch statistics, :439-441, 508-510)

@@ -14,7 +14,7 @@ namespace ptv3 {
 // thread = (one of 16 columns, one of 16 slab lanes): lane z sums slabs z, z+16, ... in order, the 16 lane
 // sums are then added in lane order (fixed tree: deterministic)
 __global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__ slab, int nslab, int64_t n,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, int64_t n0, float* __restrict__ out1) {
   __shared__ float red[16][17];
   const int c = threadIdx.x & 15, z0 = threadIdx.x >> 4;
   const int64_t j = (int64_t)blockIdx.x * 16 + c;
@@ -27,12 +27,14 @@ __global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__
     float t = 0.f;
 #pragma unroll
     for (int z = 0; z < 16; ++z) t += red[z][c];
-    out[j] = t;
+    if (j < n0) out[j] = t; else out1[j - n0] = t;   // entries n0 .. n-1 of a slab row go to a second buffer
   }
 }
 
-static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, s, slab, nslab, n, out);
+static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStream_t s, int64_t n0 = -1,
+                     float* out1 = nullptr) {
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, s, slab, nslab, n, out,
+                     n0 < 0 ? n : n0, out1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -48,6 +50,7 @@ static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStr
 // ------------------------------------------------------------------------------------------------
 struct TnArgs {
   const void* dy; const void* x; const int32_t* nbr; float* out;
+  float* dbias;   // NULL, or where chunk z writes its column sums of dy: dbias + z * slab_stride (cout floats)
   int64_t m, rows_per_chunk, slab_stride;
   int cout, cin, kvol, tiles_c;
 };
@@ -96,8 +99,20 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
       }
     }
   };
+  // bias gradient (column sums of dy) as a by-product of the staging: this thread sees channels o0 + 4cg .. +3 of
+  // every row block; only the workgroups of the first input-channel tile / first tap keep them
+  const bool want_b = a.dbias != nullptr && tc == 0 && tap == 0;
+  float bs[4] = {0.f, 0.f, 0.f, 0.f};
   fetch(r0);
   for (int64_t rblk = r0; rblk < r1; rblk += TN_RB) {
+    if (want_b) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float t4[4];
+        unpack4<T>(ra[u], t4);
+        bs[0] += t4[0]; bs[1] += t4[1]; bs[2] += t4[2]; bs[3] += t4[3];
+      }
+    }
     {
       const T* ea[4] = {reinterpret_cast<const T*>(&ra[0]), reinterpret_cast<const T*>(&ra[1]),
                         reinterpret_cast<const T*>(&ra[2]), reinterpret_cast<const T*>(&ra[3])};
@@ -125,6 +140,18 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (p < nto && q < ntc) acc[p][q] = mma16<T>(fa[p], fb[q], acc[p][q]);
+    __syncthreads();
+  }
+  if (want_b) {   // block-uniform
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sR[rg * 64 + 4 * cg + e] = bs[e];
+    __syncthreads();
+    if (threadIdx.x < 64 && o0 + (int)threadIdx.x < a.cout) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += sR[r * 64 + threadIdx.x];
+      a.dbias[(int64_t)blockIdx.z * a.slab_stride + o0 + threadIdx.x] = t;
+    }
     __syncthreads();
   }
   // sum the four waves' partial tiles: waves 1..3 hand theirs to wave 0 through LDS, one at a time
@@ -474,11 +501,12 @@ using namespace ptv3;
 extern "C" size_t ptv3_gemm_tn_workspace_bytes(int64_t m, int cout, int cin, int kvol) {
   int64_t rpc;
   const int64_t ns = tn_chunks(m, cout, cin, kvol, &rpc);
-  return ns > 1 ? (size_t)ns * cout * kvol * cin * sizeof(float) : 0;
+  return ns > 1 ? (size_t)ns * ((size_t)cout * kvol * cin + cout) * sizeof(float) : 0;
 }
 
-extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, int64_t m, int cout,
-                            int cin, int kvol, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, float* dbias, int64_t m,
+                            int cout, int cin, int kvol, int dtype, void* workspace, size_t workspace_bytes,
+                            void* stream) {
   BWD_DTYPE_CHECK("gemm_tn");
   PTV3_REQUIRE(cout > 0 && cin > 0 && kvol >= 1 && m >= 0, "gemm_tn: bad shape m=%lld cout=%d cin=%d kvol=%d",
                (long long)m, cout, cin, kvol);
@@ -487,6 +515,7 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
   const int64_t nw = (int64_t)cout * kvol * cin;
   if (m == 0) {
     if (hipMemsetAsync(dw, 0, nw * sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
+    if (dbias && hipMemsetAsync(dbias, 0, (size_t)cout * sizeof(float), s) != hipSuccess) return PTV3_ERR_LAUNCH;
     return PTV3_OK;
   }
   PTV3_REQUIRE(cout % 4 == 0 && cin % 4 == 0, "gemm_tn: cout=%d and cin=%d must be multiples of 4", cout, cin);
@@ -495,13 +524,18 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
   PTV3_REQUIRE(workspace_bytes >= ptv3_gemm_tn_workspace_bytes(m, cout, cin, kvol), "gemm_tn: workspace too small");
   TnArgs a;
   a.dy = dy; a.x = x; a.nbr = nbr;
+  // several row chunks: slab z = [dW (nw) | column sums of dy (cout)], summed in chunk order afterwards
   a.out = ns > 1 ? (float*)workspace : dw;
-  a.m = m; a.rows_per_chunk = rpc; a.slab_stride = nw;
+  a.dbias = !dbias ? nullptr : (ns > 1 ? (float*)workspace + nw : dbias);
+  a.m = m; a.rows_per_chunk = rpc; a.slab_stride = ns > 1 ? nw + (dbias ? cout : 0) : 0;
   a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)cdiv(cin, 64);
   dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)kvol, (unsigned)ns);
   if (dtype == PTV3_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), 0, s, a);
-  if (ns > 1) slab_sum((const float*)workspace, (int)ns, nw, dw, s);
+  if (ns > 1) {
+    if (dbias) slab_sum((const float*)workspace, (int)ns, nw + cout, dw, s, nw, dbias);
+    else slab_sum((const float*)workspace, (int)ns, nw, dw, s);
+  }
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -62,11 +62,15 @@ class LinearFn(Function):
             dyp = _pad_cols(dy, gran)
             wt = ctx.wt if ctx.wt is not None else _pad_cols(ctx.w[:, :ctx.cin].t().contiguous(), gran)
             dx = ops.gemm(dyp, wt)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # the kernel wants cout in multiples of 4 (a class count like 13 or 19 is not): zero columns, dropped again
             dy4 = _pad_cols(dy, 4)
-            dw = ops.gemm_tn(dy4, xp)[:dy.shape[1], :ctx.cin].to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dw = ops.gemm_tn(dy4, xp, with_bias=want_b)     # the bias gradient rides on the same pass over dy
+            if want_b:
+                dw, db = dw[0], dw[1][:dy.shape[1]]
+            dw = dw[:dy.shape[1], :ctx.cin].to(weight.dtype)
+        elif want_b:
             db = ops.col_reduce(dy)
         return dx, dw, db
 
@@ -106,10 +110,14 @@ class SubMConvFn(Function):
                     w = torch.nn.functional.pad(w, (0, dyp.shape[1] - cout))
                 wt = w.reshape(cin, -1).to(dy.dtype).contiguous()
             dx = ops.gemm(dyp, wt, nbr=nbr, kvol=kvol, row_order=row_order)
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dy, xp, nbr, kvol).view(cout, kvol, xp.shape[1])[:, :, :cin]
+            dw = ops.gemm_tn(dy, xp, nbr, kvol, with_bias=want_b)
+            if want_b:
+                dw, db = dw
+            dw = dw.view(cout, kvol, xp.shape[1])[:, :, :cin]
             dw = dw.reshape(weight.shape).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif want_b:
             db = ops.col_reduce(dy)
         return dx, dw, db, None, None
 
@@ -332,8 +340,16 @@ def cluster_gather(feat, cluster, order0, seg_start):
 # One Function per Block for training: the same kernels as the per-layer Functions above, issued back to back
 # without going through the autograd engine between them (13 Function round trips per block become one).
 # -------------------------------------------------------------------------------------------------
-def _lin_fwd(x, w, b):
-    return ops.gemm(x, w, bias=None if b is None else b.detach().float().contiguous())
+def _lin_fwd(x, w, b, res=None):
+    return ops.gemm(x, w, bias=None if b is None else b.detach().float().contiguous(), res=res)
+
+
+def _branch_add(skip, branch_in, w, b, mask):
+    """skip + mask * linear(branch_in): without DropPath the residual rides in the GEMM epilogue, with it the
+    per-point factor and the sum are one element-wise pass."""
+    if mask is None:
+        return _lin_fwd(branch_in, w, b, res=skip)
+    return torch.addcmul(skip, _lin_fwd(branch_in, w, b), mask)
 
 
 def _lin_bwd(dy, x, w_pair, gran):
@@ -342,7 +358,8 @@ def _lin_bwd(dy, x, w_pair, gran):
     if wt is None:
         wt = _pad_cols(w_cast.t().contiguous(), gran)
     dx = ops.gemm(_pad_cols(dy, gran), wt)
-    return dx, ops.gemm_tn(dy, x), ops.col_reduce(dy)
+    dw, db = ops.gemm_tn(dy, x, with_bias=True)
+    return dx, dw, db
 
 
 class BlockFn(Function):
@@ -373,13 +390,11 @@ class BlockFn(Function):
         t3 = ops.layernorm(f1, f32(n1_g), f32(n1_b), eps)
         qkv = _lin_fwd(t3, w_qkv[0], qkv_b)
         a = ops.window_attention_any(qkv, wo, wi, heads, patch, scale, cu)
-        p = _lin_fwd(a, w_proj[0], proj_b)
-        f2 = f1 + (p if mask1 is None else p * mask1)
+        f2 = _branch_add(f1, a, w_proj[0], proj_b, mask1)
         t5 = ops.layernorm(f2, f32(n2_g), f32(n2_b), eps)
         h0 = _lin_fwd(t5, w_fc1[0], fc1_b)
         h = ops.affine_act(h0, None, None, ops.ACT_GELU)
-        m = _lin_fwd(h, w_fc2[0], fc2_b)
-        out = f2 + (m if mask2 is None else m * mask2)
+        out = _branch_add(f2, h, w_fc2[0], fc2_b, mask2)
         ctx.save_for_backward(xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2,
                               conv_w, ln0_g, n1_g, n2_g, cu)
         ctx.cast = (w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2)
@@ -419,8 +434,8 @@ class BlockFn(Function):
             wt = w_conv[0].view(cout, kvol, cin).flip(1).permute(2, 1, 0).reshape(cin, -1).contiguous()
         # same: the conv read `feat` itself, its input gradient lands on df1 in the GEMM epilogue
         dxin = ops.gemm(_pad_cols(dc1, gran), wt, nbr=nbr, kvol=kvol, row_order=row_order, res=df1 if same else None)
-        dW_conv = ops.gemm_tn(dc1, xin, nbr, kvol).view(conv_w.shape)
-        db_conv = ops.col_reduce(dc1)
+        dW_conv, db_conv = ops.gemm_tn(dc1, xin, nbr, kvol, with_bias=True)
+        dW_conv = dW_conv.view(conv_w.shape)
         dfeat = dxin if same else df1
         c = lambda t: t.to(pd)  # noqa: E731
         return (dfeat, None if same else dxin, c(dW_conv), c(db_conv), c(dW_lin), c(db_lin), c(dg0), c(db0), c(dg1),

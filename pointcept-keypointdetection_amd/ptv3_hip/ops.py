@@ -467,8 +467,9 @@ def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
 
 
-def gemm_tn(dy, x, nbr=None, kvol=1):
-    """dW (cout, kvol*cin) fp32 = dy^T . gather(x): weight gradient of a Linear (kvol=1) or SubMConv3d."""
+def gemm_tn(dy, x, nbr=None, kvol=1, with_bias=False):
+    """dW (cout, kvol*cin) fp32 = dy^T . gather(x): weight gradient of a Linear (kvol=1) or SubMConv3d.
+    with_bias: -> (dW, db) with db (cout) fp32 = column sums of dy from the same pass."""
     _chk(dy, "dy", _F, 2)
     _chk(x, "x", dy.dtype, 2)
     _chk(nbr, "nbr", torch.int32, 2)
@@ -478,11 +479,12 @@ def gemm_tn(dy, x, nbr=None, kvol=1):
             (nbr is None and x.shape[0] != m):
         raise RuntimeError("gemm_tn: shape mismatch")
     dw = torch.empty((cout, kvol * cin), dtype=torch.float32, device=dy.device)
+    db = torch.empty(cout, dtype=torch.float32, device=dy.device) if with_bias else None
     nb = lib.ptv3_gemm_tn_workspace_bytes(m, cout, cin, int(kvol))
     ws = _ws(nb, dy.device)
-    lib.check(lib.ptv3_gemm_tn(_p(dy), _p(x), _p(nbr), _p(dw), m, cout, cin, int(kvol), _dt(dy), _p(ws), nb,
+    lib.check(lib.ptv3_gemm_tn(_p(dy), _p(x), _p(nbr), _p(dw), _p(db), m, cout, cin, int(kvol), _dt(dy), _p(ws), nb,
                                _stream()), "ptv3_gemm_tn")
-    return dw
+    return (dw, db) if with_bias else dw
 
 
 def col_reduce(a, b=None, mu=None, rs=None, mode=0):
