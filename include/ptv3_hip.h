@@ -375,6 +375,42 @@ int ptv3_window_attn_rpe_bwd(const void* qkv, const void* out, const void* dout,
                              const int32_t* win_inverse, const int32_t* grid_coord, const float* rpe_table,
                              int pos_bnd, void* dqkv, float* dtable, int64_t n, int64_t n_pad, int c, int heads,
                              int patch, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- one Block, training, as two native calls -------------------------------------------------------------------
+ * Block.forward (point_transformer_v3m1_base.py:318-338, pre-norm, LayerNorm / GELU) and what torch autograd derives
+ * from it, each as ONE C call issuing the same kernels as the per-op entry points above would (ptv3_hip/autograd.py
+ * BlockFn composes those and is this descriptor's checker):
+ *   c = LN0(lin(conv(conv_feat))); f1 = feat + c; f2 = f1 + mask1 * proj(attn(qkv(LN1(f1))));
+ *   out = f2 + mask2 * fc2(GELU(fc1(LN2(f2))))
+ * All (n, .) tensors in `dtype`, vectors / gradients of parameters fp32.  w_*: (cout, K) as ptv3_gemm's w; wt_*
+ * (backward): W^T (cin, cout) of the linears, the mirrored-tap transposed weight (cin, kvol*cout) of the conv.
+ * conv_feat NULL: the xCPE conv reads feat (every block but the first decoder block of a stage).  mask1 / mask2 (n) in
+ * dtype or NULL: per-point DropPath factors.  cu_seqlens NULL: uniform windows of `patch` slots.
+ * fwd writes c1 .. out; bwd reads them plus dout and writes dfeat (and dconv_feat), dw_* (cout, K), db_* (cout),
+ * dln0/1/2 (2, c) = [dgamma | dbeta] of the three LayerNorms.  workspace: ptv3_block_train_workspace_bytes(). */
+typedef struct ptv3_block_train {
+  int64_t n, n_pad;
+  int32_t c, hidden, heads, patch, kvol, num_windows, dtype, reserved;
+  float scale, eps;
+  double sum_len_sq;
+  const int32_t *nbr, *row_order, *win_order, *win_inverse, *cu_seqlens;
+  const void *feat, *conv_feat;
+  const void *w_conv, *w_lin, *w_qkv, *w_proj, *w_fc1, *w_fc2;
+  const void *wt_conv, *wt_lin, *wt_qkv, *wt_proj, *wt_fc1, *wt_fc2;
+  const float *b_conv, *b_lin, *b_qkv, *b_proj, *b_fc1, *b_fc2, *g0, *b0, *g1, *b1, *g2, *b2;
+  const void *mask1, *mask2;
+  void *c1, *c2, *f1, *t3, *qkv, *a, *f2, *t5, *h0, *h, *out;
+  const void* dout;
+  void *dfeat, *dconv_feat;
+  float *dw_conv, *dw_lin, *dw_qkv, *dw_proj, *dw_fc1, *dw_fc2;
+  float *db_conv, *db_lin, *db_qkv, *db_proj, *db_fc1, *db_fc2;
+  float *dln0, *dln1, *dln2;
+  void* workspace;
+  size_t workspace_bytes;
+} ptv3_block_train;
+size_t ptv3_block_train_workspace_bytes(const ptv3_block_train* block, int backward);
+int ptv3_block_train_fwd(const ptv3_block_train* block, void* stream);
+int ptv3_block_train_bwd(const ptv3_block_train* block, void* stream);
+
 /* fused multi-tensor AdamW (torch.optim.AdamW semantics; pointcept/utils/optimizer.py builds it with one
  * extra "block" parameter group): a device table of ptv3_adamw_entry_bytes()-sized entries, filled on the
  * host by ptv3_adamw_fill_entry; entry i owns blocks [first_block_i, first_block_i + ceil(numel_i / chunk)).

@@ -6,10 +6,14 @@ the C ABI (include/ptv3_hip.h, "training: backward kernels").  torch supplies th
 parameter tensors (fp32 masters; activations may be bf16: weights are cast per call, weight gradients are
 accumulated in fp32 by the kernels and returned in the parameter's dtype).
 """
+import ctypes
+import os
+
 import torch
 from torch.autograd import Function
 
 from . import ops
+from .lib import lib
 
 
 def _wmat(w, dtype, cin_pad=None):
@@ -443,6 +447,116 @@ class BlockFn(Function):
                 c(db_fc2), None, None, None, None, None, None, None, None, None, None, None)
 
 
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32_ptr(p, name):
+    if p.dtype != torch.float32 or not p.is_contiguous():
+        raise TypeError(f"BlockNativeFn: {name} must be a contiguous fp32 parameter")
+    return p.data_ptr()
+
+
+def _transposed(pair, kvol):
+    """(natural, transposed) weight pair of _weights(); the transposed one is built here when no optimizer keeps it"""
+    nat, t = pair
+    if t is None:
+        if kvol == 1:
+            t = nat.t().contiguous()
+        else:
+            cout = nat.shape[0]
+            t = nat.view(cout, kvol, -1).flip(1).permute(2, 1, 0).reshape(nat.shape[1] // kvol, -1).contiguous()
+    return nat, t
+
+
+class BlockNativeFn(Function):
+    """BlockFn with the forward and the backward each issued by ONE native call (ptv3_block_train_fwd / _bwd, csrc/
+    block_train.hip): same kernels, same order, same results - the ~12 + ~30 launches per block no longer pass through
+    Python wrappers one by one (a training step of the fork model was host-bound on them)."""
+
+    @staticmethod
+    def forward(ctx, feat, conv_feat, conv_w, conv_b, lin_w, lin_b, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b,
+                proj_w, proj_b, n2_g, n2_b, fc1_w, fc1_b, fc2_w, fc2_b, nbr, row_order, wo, wi, heads, patch, scale,
+                mask1, mask2, eps, cu=None):
+        from .lib import BlockTrain
+        dt = feat.dtype
+        feat = feat.contiguous()
+        xin = None if conv_feat is None else conv_feat.contiguous()
+        n, c = feat.shape
+        hidden = fc1_w.shape[0]
+        kvol = nbr.shape[1]
+        dev = feat.device
+        taped = any(ctx.needs_input_grad)      # the transposed weights are only read by the backward
+        ws = [_transposed(_weights(w, dt), kvol if i == 0 else 1) if taped else (_weights(w, dt)[0], None)
+              for i, w in enumerate((conv_w, lin_w, qkv_w, proj_w, fc1_w, fc2_w))]
+        b = BlockTrain()
+        b.n, b.n_pad, b.c, b.hidden, b.heads, b.patch, b.kvol = n, wo.shape[0], c, hidden, int(heads), int(patch), kvol
+        b.num_windows = 0 if cu is None else cu.numel() - 1
+        b.dtype, b.scale, b.eps, b.sum_len_sq = ops._dt(feat), float(scale), float(eps), 0.0
+        b.nbr, b.row_order, b.win_order, b.win_inverse, b.cu_seqlens = _ptr(nbr), _ptr(row_order), _ptr(wo), _ptr(wi), _ptr(cu)
+        b.feat, b.conv_feat = feat.data_ptr(), _ptr(xin)
+        (b.w_conv, b.wt_conv), (b.w_lin, b.wt_lin), (b.w_qkv, b.wt_qkv), (b.w_proj, b.wt_proj), (b.w_fc1, b.wt_fc1), \
+            (b.w_fc2, b.wt_fc2) = [(_ptr(w), _ptr(t)) for w, t in ws]
+        for name, p in (("b_conv", conv_b), ("b_lin", lin_b), ("b_qkv", qkv_b), ("b_proj", proj_b), ("b_fc1", fc1_b),
+                        ("b_fc2", fc2_b), ("g0", ln0_g), ("b0", ln0_b), ("g1", n1_g), ("b1", n1_b), ("g2", n2_g),
+                        ("b2", n2_b)):
+            setattr(b, name, _f32_ptr(p, name))
+        b.mask1, b.mask2 = _ptr(mask1), _ptr(mask2)
+        # activations the backward needs: one allocation, carved into (n, c) x 9, (n, 3c), (n, hidden) x 2
+        flat = torch.empty(n * (9 * c + 3 * c + 2 * hidden), dtype=dt, device=dev)
+        views, at = {}, 0
+        for name, width in (("c1", c), ("c2", c), ("f1", c), ("t3", c), ("a", c), ("f2", c), ("t5", c), ("out", c),
+                            ("qkv", 3 * c), ("h0", hidden), ("h", hidden)):
+            views[name] = flat[at:at + n * width].view(n, width)
+            setattr(b, name, views[name].data_ptr())
+            at += n * width
+        nb = lib.ptv3_block_train_workspace_bytes(ctypes.byref(b), 0)
+        wsb = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        b.workspace, b.workspace_bytes = wsb.data_ptr(), nb
+        lib.check(lib.ptv3_block_train_fwd(ctypes.byref(b), ops._stream()), "ptv3_block_train_fwd")
+        ctx.save_for_backward(feat, xin, nbr, row_order, wo, wi, cu, mask1, mask2)
+        ctx.block, ctx.flat, ctx.keep = b, flat, (ws, conv_w, (conv_b, lin_b, qkv_b, proj_b, fc1_b, fc2_b, ln0_g, ln0_b,
+                                                                n1_g, n1_b, n2_g, n2_b))
+        ctx.shapes = (n, c, hidden, kvol, conv_w.shape)
+        return views["out"]
+
+    @staticmethod
+    def backward(ctx, dout):
+        b, (ws, conv_w, _) = ctx.block, ctx.keep
+        n, c, hidden, kvol, conv_shape = ctx.shapes
+        same = ctx.saved_tensors[1] is None
+        dout = dout.contiguous()
+        dev, dt = dout.device, dout.dtype
+        f32 = dict(dtype=torch.float32, device=dev)
+        dfeat = torch.empty((n, c), dtype=dt, device=dev)
+        dconv = None if same else torch.empty((n, c), dtype=dt, device=dev)
+        # parameter gradients: one fp32 allocation (weights, biases, the three LayerNorm (2, c) pairs)
+        sizes = (c * kvol * c, c * c, 3 * c * c, c * c, hidden * c, c * hidden, c, c, 3 * c, c, hidden, c, 2 * c, 2 * c, 2 * c)
+        flat = torch.empty(sum(sizes), **f32)
+        parts, at = [], 0
+        for sz in sizes:
+            parts.append(flat[at:at + sz])
+            at += sz
+        for name, t in zip(("dw_conv", "dw_lin", "dw_qkv", "dw_proj", "dw_fc1", "dw_fc2", "db_conv", "db_lin", "db_qkv",
+                            "db_proj", "db_fc1", "db_fc2", "dln0", "dln1", "dln2"), parts):
+            setattr(b, name, t.data_ptr())
+        b.dout, b.dfeat, b.dconv_feat = dout.data_ptr(), dfeat.data_ptr(), _ptr(dconv)
+        nb = lib.ptv3_block_train_workspace_bytes(ctypes.byref(b), 1)
+        wsb = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        b.workspace, b.workspace_bytes = wsb.data_ptr(), nb
+        lib.check(lib.ptv3_block_train_bwd(ctypes.byref(b), ops._stream()), "ptv3_block_train_bwd")
+        (dw_conv, dw_lin, dw_qkv, dw_proj, dw_fc1, dw_fc2, db_conv, db_lin, db_qkv, db_proj, db_fc1, db_fc2, dln0, dln1,
+         dln2) = parts
+        ctx.flat = None
+        return (dfeat, dconv, dw_conv.view(conv_shape), db_conv, dw_lin.view(c, c), db_lin, dln0[:c], dln0[c:], dln1[:c],
+                dln1[c:], dw_qkv.view(3 * c, c), db_qkv, dw_proj.view(c, c), db_proj, dln2[:c], dln2[c:],
+                dw_fc1.view(hidden, c), db_fc1, dw_fc2.view(c, hidden), db_fc2, None, None, None, None, None, None, None,
+                None, None, None, None)
+
+
+_NATIVE_BLOCK = os.environ.get("PTV3_BLOCK_NATIVE", "1") != "0"
+
+
 def block(feat, conv_feat, blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps, cu=None):
-    return BlockFn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps,
-                         cu)
+    fn = BlockNativeFn if _NATIVE_BLOCK and blk_params[0].dtype == torch.float32 else BlockFn
+    return fn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps, cu)

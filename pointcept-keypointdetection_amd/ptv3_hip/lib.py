@@ -15,6 +15,26 @@ def library_path():
 
 
 P = c_void_p
+
+
+class BlockTrain(ctypes.Structure):
+    """struct ptv3_block_train of include/ptv3_hip.h (field for field)"""
+    _fields_ = ([("n", c_int64), ("n_pad", c_int64)] +
+                [(k, ctypes.c_int32) for k in ("c", "hidden", "heads", "patch", "kvol", "num_windows", "dtype", "reserved")] +
+                [("scale", c_float), ("eps", c_float), ("sum_len_sq", c_double)] +
+                [(k, P) for k in ("nbr", "row_order", "win_order", "win_inverse", "cu_seqlens", "feat", "conv_feat",
+                                  "w_conv", "w_lin", "w_qkv", "w_proj", "w_fc1", "w_fc2",
+                                  "wt_conv", "wt_lin", "wt_qkv", "wt_proj", "wt_fc1", "wt_fc2",
+                                  "b_conv", "b_lin", "b_qkv", "b_proj", "b_fc1", "b_fc2", "g0", "b0", "g1", "b1", "g2", "b2",
+                                  "mask1", "mask2",
+                                  "c1", "c2", "f1", "t3", "qkv", "a", "f2", "t5", "h0", "h", "out",
+                                  "dout", "dfeat", "dconv_feat",
+                                  "dw_conv", "dw_lin", "dw_qkv", "dw_proj", "dw_fc1", "dw_fc2",
+                                  "db_conv", "db_lin", "db_qkv", "db_proj", "db_fc1", "db_fc2",
+                                  "dln0", "dln1", "dln2", "workspace")] +
+                [("workspace_bytes", c_size_t)])
+
+
 # name -> (restype, argtypes); must list every symbol include/ptv3_hip.h declares
 SIGNATURES = {
     "ptv3_last_error": (c_char_p, []),
@@ -54,6 +74,9 @@ SIGNATURES = {
     "ptv3_forward": (c_int, [P, P, c_int, P, P, c_size_t, P]),
     "ptv3_executor_create": (c_void_p, []),
     "ptv3_executor_destroy": (c_int, [P]),
+    "ptv3_block_train_workspace_bytes": (c_size_t, [P, c_int]),
+    "ptv3_block_train_fwd": (c_int, [P, P]),
+    "ptv3_block_train_bwd": (c_int, [P, P]),
     "ptv3_gemm_tn_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "ptv3_gemm_tn": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "ptv3_col_reduce_workspace_bytes": (c_size_t, [c_int64, c_int]),

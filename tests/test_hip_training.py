@@ -410,3 +410,42 @@ def test_fused_adamw_state_dict_round_trip_with_torch_adamw(dev):
         assert (a - b).abs().max().item() < 2e-6
     st5 = o5.state_dict()["state"]   # keyed by parameter index
     assert [float(st5[i]["step"]) for i in range(4)] == [4.0, 2.0, 4.0, 4.0]
+
+
+@pytest.mark.parametrize("dtype,drop_path,flash", [(torch.float32, 0.0, False), (torch.bfloat16, 0.0, True),
+                                                   (torch.bfloat16, 0.3, False)])
+def test_native_block_calls_equal_the_per_op_composition(dev, dtype, drop_path, flash):
+    """ptv3_block_train_fwd / _bwd (one native call per block and direction) against BlockFn, the same block composed
+    from the per-op entry points: identical kernels in identical order, so loss and every gradient are bitwise equal
+    without DropPath; with DropPath the factor is applied by one fused multiply-add here and by torch.addcmul there
+    (one bf16 rounding apart at most).  Covers uniform and ragged (enable_flash) windows and the first decoder block,
+    whose conv reads the skip tensor."""
+    import ptv3_scenes as S
+    from ptv3_hip import autograd as A
+    cfg = dict(TINY_CFG, drop_path=drop_path, enable_flash=flash)
+    data = S.make_batch([1300, 40, 900], in_channels=4, extent=96, seed=4, with_target=6)
+    results = []
+    for native in (True, False):
+        torch.manual_seed(77)
+        model = _build(cfg, hidden_dim=32)
+        _perturb_stats(model)
+        model = model.to(dev).train()
+        model.backbone.compute_dtype = dtype
+        A._NATIVE_BLOCK = native
+        try:
+            torch.manual_seed(5)
+            out = model({k: v.to(dev) for k, v in data.items()})
+            out["loss"].backward()
+        finally:
+            A._NATIVE_BLOCK = True
+        results.append((out["loss"].detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters()}))
+    (l1, g1), (l0, g0) = results
+    if drop_path == 0.0:
+        assert torch.equal(l1, l0)
+        for n in g0:
+            assert torch.equal(g1[n], g0[n]), n
+    else:
+        assert abs(l1.item() - l0.item()) < 2e-2 * max(1.0, abs(l0.item()))
+        gmax = max(g.abs().max().item() for g in g0.values())
+        for n in g0:
+            assert (g1[n] - g0[n]).abs().max().item() <= 0.05 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
