@@ -4,6 +4,7 @@
 //   gather backward of SerializedPooling / SerializedUnpooling.
 // All reductions over points are deterministic: fixed row chunks -> fp32 slabs -> slab-ordered sum.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -55,15 +56,19 @@ struct TnArgs {
   int cout, cin, kvol, tiles_c;
 };
 
-constexpr int TN_RB = 64;           // rows per staged block (= 4 waves x one 16-row k-step)
-constexpr int TN_LS = TN_RB + 4;    // LDS row stride in elements (bank spread, keeps 8/16-byte alignment)
-
-template <typename T>
+// Rows per staged block RB (k-steps of 16 rows, RB/64 per wave) and LDS row stride LS (elements).  One block = one
+// round of global loads -> LDS -> barrier -> MFMAs -> barrier.  LS / 2 (bf16 dwords) = 34 modulo 64 keeps the fragment
+// reads of a half wave on 32 distinct bank pairs, and = 2 modulo 16 holds the transposing stores to 2-way conflicts
+// (an even stride cannot do better: the stores are 8-byte pieces of rows 4 channels apart).
+constexpr int TN_RB_MAX = 128;
+template <typename T, int RB, int LS>
 __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   typedef typename Vec4<T>::type V4;
-  __shared__ __attribute__((aligned(16))) T sA[64 * TN_LS];   // [o][row]
-  __shared__ __attribute__((aligned(16))) T sB[64 * TN_LS];   // [c][row]
-  __shared__ float sR[64 * 64];                                // cross-wave reduction
+  constexpr int NJ = RB / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
+  T* sA = reinterpret_cast<T*>(tn_smem);          // [o][row]
+  T* sB = sA + 64 * LS;                           // [c][row]
+  float* sR = reinterpret_cast<float*>(tn_smem);  // cross-wave reduction, after the last block
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,66 +85,87 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging: each thread owns a 4-row x 4-channel patch of both operands (rows 4*rg .. +3, channels 4*cg .. +3),
-  // transposes it in registers and stores 4 x (4 consecutive rows of one channel) = four 8/16-byte LDS stores per
-  // operand instead of sixteen element stores
+  // staging: each thread owns NJ 4-row x 4-channel patches of both operands (rows 64j + 4rg .. +3, channels 4cg .. +3),
+  // transposes them in registers and stores 4 x (4 consecutive rows of one channel) per patch
   const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
-  V4 ra[4], rb[4];
+  const bool oka = o0 + 4 * cg < a.cout, okb = c0 + 4 * cg < a.cin;
+  V4 ra[NJ][4], rb[NJ][4];
+  // Every load is issued unconditionally from an in-range address and the value dropped afterwards: a load inside a
+  // branch makes the compiler wait for ALL outstanding loads (vmcnt(0)) at the branch, which serialised the
+  // index -> row chains of a thread's rows; this way the indices of all rows are in flight together, then all rows.
+  const int64_t rlast = r1 - 1;                    // r1 > r0: a chunk is never empty
+  const int ca = oka ? o0 + 4 * cg : 0, cb = okb ? c0 + 4 * cg : 0;
   auto fetch = [&](int64_t rblk) {
+    int src[NJ][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t r = rblk + 4 * rg + u;
-      ra[u] = zero4<T>();
-      rb[u] = zero4<T>();
-      if (r < r1) {
-        if (o0 + 4 * cg < a.cout) ra[u] = *reinterpret_cast<const V4*>(dy + r * a.cout + o0 + 4 * cg);
-        int64_t src = r;
-        if (a.nbr) src = a.nbr[r * a.kvol + tap];
-        if (src >= 0 && c0 + 4 * cg < a.cin) rb[u] = *reinterpret_cast<const V4*>(x + src * a.cin + c0 + 4 * cg);
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = rblk + 64 * j + 4 * rg + u;
+        const int64_t rc = r < r1 ? r : rlast;
+        src[j][u] = a.nbr ? a.nbr[rc * a.kvol + tap] : (int)rc;
+        ra[j][u] = *reinterpret_cast<const V4*>(dy + rc * a.cout + ca);
       }
-    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t r = rblk + 64 * j + 4 * rg + u;
+        const bool live = r < r1;
+        const int sidx = src[j][u];
+        rb[j][u] = *reinterpret_cast<const V4*>(x + (int64_t)(sidx >= 0 ? sidx : 0) * a.cin + cb);
+        if (!(live && oka)) ra[j][u] = zero4<T>();
+        if (!(live && okb && sidx >= 0)) rb[j][u] = zero4<T>();
+      }
   };
   // bias gradient (column sums of dy) as a by-product of the staging: this thread sees channels o0 + 4cg .. +3 of
   // every row block; only the workgroups of the first input-channel tile / first tap keep them
   const bool want_b = a.dbias != nullptr && tc == 0 && tap == 0;
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
   fetch(r0);
-  for (int64_t rblk = r0; rblk < r1; rblk += TN_RB) {
+  for (int64_t rblk = r0; rblk < r1; rblk += RB) {
     if (want_b) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float t4[4];
-        unpack4<T>(ra[u], t4);
-        bs[0] += t4[0]; bs[1] += t4[1]; bs[2] += t4[2]; bs[3] += t4[3];
-      }
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float t4[4];
+          unpack4<T>(ra[j][u], t4);
+          bs[0] += t4[0]; bs[1] += t4[1]; bs[2] += t4[2]; bs[3] += t4[3];
+        }
     }
-    {
-      const T* ea[4] = {reinterpret_cast<const T*>(&ra[0]), reinterpret_cast<const T*>(&ra[1]),
-                        reinterpret_cast<const T*>(&ra[2]), reinterpret_cast<const T*>(&ra[3])};
-      const T* eb[4] = {reinterpret_cast<const T*>(&rb[0]), reinterpret_cast<const T*>(&rb[1]),
-                        reinterpret_cast<const T*>(&rb[2]), reinterpret_cast<const T*>(&rb[3])};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const T* ea[4] = {reinterpret_cast<const T*>(&ra[j][0]), reinterpret_cast<const T*>(&ra[j][1]),
+                        reinterpret_cast<const T*>(&ra[j][2]), reinterpret_cast<const T*>(&ra[j][3])};
+      const T* eb[4] = {reinterpret_cast<const T*>(&rb[j][0]), reinterpret_cast<const T*>(&rb[j][1]),
+                        reinterpret_cast<const T*>(&rb[j][2]), reinterpret_cast<const T*>(&rb[j][3])};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         T ta[4] = {ea[0][e], ea[1][e], ea[2][e], ea[3][e]};
         T tb[4] = {eb[0][e], eb[1][e], eb[2][e], eb[3][e]};
-        *reinterpret_cast<V4*>(sA + (4 * cg + e) * TN_LS + 4 * rg) = *reinterpret_cast<const V4*>(ta);
-        *reinterpret_cast<V4*>(sB + (4 * cg + e) * TN_LS + 4 * rg) = *reinterpret_cast<const V4*>(tb);
+        *reinterpret_cast<V4*>(sA + (4 * cg + e) * LS + 64 * j + 4 * rg) = *reinterpret_cast<const V4*>(ta);
+        *reinterpret_cast<V4*>(sB + (4 * cg + e) * LS + 64 * j + 4 * rg) = *reinterpret_cast<const V4*>(tb);
       }
     }
     __syncthreads();
-    if (rblk + TN_RB < r1) fetch(rblk + TN_RB);
-    // this wave's k-step: rows 16*wave .. 16*wave+15 of the block
-    V4 fa[4], fb[4];
+    if (rblk + RB < r1) fetch(rblk + RB);
+    // this wave's k-steps: rows 16 * (wave + 4 ks) .. +15 of the block
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if (p < nto) fa[p] = *reinterpret_cast<const V4*>(sA + (16 * p + i) * TN_LS + 16 * wave + 4 * g);
-      if (p < ntc) fb[p] = *reinterpret_cast<const V4*>(sB + (16 * p + i) * TN_LS + 16 * wave + 4 * g);
+    for (int ks = 0; ks < NJ; ++ks) {
+      const int row = 16 * (wave + 4 * ks) + 4 * g;
+      V4 fa[4], fb[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (p < nto) fa[p] = *reinterpret_cast<const V4*>(sA + (16 * p + i) * LS + row);
+        if (p < ntc) fb[p] = *reinterpret_cast<const V4*>(sB + (16 * p + i) * LS + row);
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (p < nto && q < ntc) acc[p][q] = mma16<T>(fa[p], fb[q], acc[p][q]);
     }
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (p < nto && q < ntc) acc[p][q] = mma16<T>(fa[p], fb[q], acc[p][q]);
     __syncthreads();
   }
   if (want_b) {   // block-uniform
@@ -194,13 +220,19 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 }
 
 static int64_t tn_chunks(int64_t m, int cout, int cin, int kvol, int64_t* rows_per_chunk) {
-  // enough workgroups to fill the chip (tiles x taps x chunks >= ~1024) but at most 64 slabs;
-  // chunks are multiples of the 64-row staging block
+  // Row chunks (= fp32 slabs, summed in order afterwards).  A workgroup's time is rounds of load -> LDS -> MFMA whose
+  // latency nothing inside the workgroup hides, so the chip wants MANY workgroups (tiles x taps x chunks ~ 2048, eight
+  // per CU) of a few rounds each rather than a few long ones: with the earlier cap of 64 chunks the weight gradient of a
+  // 100k x 96 x 32 linear ran on 126 workgroups (50 us for 26 MB of operands).  The slabs bound it from the other side:
+  // every chunk writes and the reduction reads cout x kvol x cin floats, held to ~32 MB per launch.
   const int64_t tiles = cdiv(cout, 64) * cdiv(cin, 64) * kvol;
-  int64_t want = cdiv(1024, tiles);
-  if (want > 64) want = 64;
-  int64_t rpc = cdiv(cdiv(m, want), TN_RB) * TN_RB;
-  if (rpc < 4 * TN_RB) rpc = 4 * TN_RB;
+  int64_t want = cdiv(2048, tiles);
+  const int64_t slab_cap = (32ll << 20) / ((int64_t)cout * cin * kvol * 4);
+  if (want > slab_cap) want = slab_cap;
+  if (want > 512) want = 512;
+  if (want < 1) want = 1;
+  int64_t rpc = cdiv(cdiv(m, want), TN_RB_MAX) * TN_RB_MAX;
+  if (rpc < 2 * TN_RB_MAX) rpc = 2 * TN_RB_MAX;
   *rows_per_chunk = rpc;
   return cdiv(m, rpc);
 }
@@ -530,8 +562,21 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
   a.m = m; a.rows_per_chunk = rpc; a.slab_stride = ns > 1 ? nw + (dbias ? cout : 0) : 0;
   a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)cdiv(cin, 64);
   dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)kvol, (unsigned)ns);
-  if (dtype == PTV3_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gemm_tn_kernel<__bf16>, grid, dim3(256), 0, s, a);
+  // LDS: two [64][LS] operand blocks; the 64 x 64 fp32 cross-wave reduction reuses them after the last block
+  static int rbsel = -1;
+  if (rbsel < 0) { const char* e = getenv("PTV3_TN_RB"); rbsel = e ? atoi(e) : 64; }
+#define TN_LAUNCH(T, RB, LS)                                                                              \
+  do {                                                                                                    \
+    constexpr size_t lds = 2 * 64 * (LS) * sizeof(T);                                                     \
+    static_assert(lds >= 64 * 64 * sizeof(float) && lds <= 64 * 1024, "gemm_tn LDS");                     \
+    hipLaunchKernelGGL((gemm_tn_kernel<T, RB, LS>), grid, dim3(256), lds, s, a);                          \
+  } while (0)
+  if (dtype == PTV3_F32) {
+    TN_LAUNCH(float, 64, 68);
+  } else {
+    if (rbsel == 128) TN_LAUNCH(__bf16, 128, 196); else TN_LAUNCH(__bf16, 64, 68);
+  }
+#undef TN_LAUNCH
   if (ns > 1) {
     if (dbias) slab_sum((const float*)workspace, (int)ns, nw + cout, dw, s, nw, dbias);
     else slab_sum((const float*)workspace, (int)ns, nw, dw, s);
