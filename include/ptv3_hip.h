@@ -430,6 +430,11 @@ int ptv3_adamw_fill_shadow(void* entry_host, void* shadow, void* shadow_t, int r
  * ptv3_adamw_step (torch.optim.AdamW keeps state["step"] per parameter: a parameter that first receives a gradient
  * later, or a resumed checkpoint, engines/hooks/misc.py:269); its bias corrections use step - step_lag. */
 int ptv3_adamw_fill_step_lag(void* entry_host, int64_t step_lag);
+/* the transposed shadows are written by a second pass of 64 x 64 tiles: entry i owns tiles [first_tile_i, first_tile_i +
+ * ptv3_adamw_shadow_tiles(rows, cols, kvol)) when it has a shadow_t and none otherwise (first_tile_i = the running sum,
+ * set on EVERY entry); total_tiles / shadow_dtype of ptv3_adamw_step describe that pass (0 tiles: no shadow_t anywhere). */
+int ptv3_adamw_shadow_tiles(int rows, int cols, int kvol);
+int ptv3_adamw_fill_first_tile(void* entry_host, int first_tile);
 /* grads_host (ntensors host array of device pointers) or NULL: this step's gradient of every table entry, overriding the
  * address stored in the table.  torch's autograd leaves a new gradient tensor on each parameter after
  * zero_grad(set_to_none=True) (no zero fill, no accumulate-add per parameter); the addresses travel as kernel arguments,
@@ -437,7 +442,8 @@ int ptv3_adamw_fill_step_lag(void* entry_host, int64_t step_lag);
  * first_block given to ptv3_adamw_fill_entry for every entry (required with grads_host). */
 int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
                     const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
-                    float grad_scale, const int32_t* first_block_host, const void* const* grads_host, void* stream);
+                    float grad_scale, const int32_t* first_block_host, const void* const* grads_host, int total_tiles,
+                    int shadow_dtype, void* stream);
 int ptv3_grad_sqnorm(const void* table_dev, int ntensors, int total_blocks, float* partial_ws, float* out,
                      const int32_t* first_block_host, const void* const* grads_host, void* stream);
 

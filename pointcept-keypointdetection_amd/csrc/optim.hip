@@ -17,7 +17,8 @@ struct AdamWTensor {
   int32_t rows, cols, kvol, shadow_dtype;
   // steps this tensor has taken fewer than the launch's `step` argument (a parameter that joined the table late, or
   // was restored from a checkpoint with its own torch.optim state["step"]): bias corrections use step - step_lag
-  int32_t step_lag, reserved;
+  int32_t step_lag;
+  int32_t first_tile;   // first 64 x 64 tile of this tensor in the transposed-shadow pass (tensors without shadow_t own none)
 };
 
 struct AdamWGroups { float lr[8], wd[8]; };
@@ -51,31 +52,84 @@ __global__ void __launch_bounds__(256) adamw_kernel(const AdamWTensor* __restric
     rsqrt_bc2 = rsqrtf(1.0f - powf(beta2, own));
   }
   const float step = lr / bc1;
-  for (int64_t j = base + threadIdx.x; j < base + ADAMW_CHUNK && j < t.numel; j += 256) {
-    const float g = t.g[j] * grad_scale;
-    float p = t.p[j] * (1.0f - lr * wd);
-    const float m = beta1 * t.m[j] + (1.0f - beta1) * g;
-    const float v = beta2 * t.v[j] + (1.0f - beta2) * g * g;
-    const float denom = sqrtf(v) * rsqrt_bc2 + eps;
-    p -= step * (m / denom);
-    t.p[j] = p; t.m[j] = m; t.v[j] = v;
-    if (t.shadow) {
-      int64_t jt = j;
-      if (t.shadow_t) {
-        const int64_t kc = (int64_t)t.kvol * t.cols;
-        const int o = (int)(j / kc);
-        const int d = (int)((j - (int64_t)o * kc) / t.cols);
-        const int c = (int)(j - (int64_t)o * kc - (int64_t)d * t.cols);
-        jt = ((int64_t)c * t.kvol + (t.kvol - 1 - d)) * t.rows + o;
+  const float decay = 1.0f - lr * wd;
+  auto update = [&](float g, float& p, float& m, float& v) {
+    g *= grad_scale;
+    p *= decay;
+    m = beta1 * m + (1.0f - beta1) * g;
+    v = beta2 * v + (1.0f - beta2) * g * g;
+    p -= step * (m / (sqrtf(v) * rsqrt_bc2 + eps));
+  };
+  const int64_t end = base + ADAMW_CHUNK < t.numel ? base + ADAMW_CHUNK : t.numel;
+  const bool vec = (t.numel & 3) == 0 &&
+                   ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m | (uintptr_t)t.v) & 15) == 0) &&
+                   (!t.shadow || ((uintptr_t)t.shadow & 15) == 0);
+  if (vec) {   // 16-byte streams: four per element in, three (+ the shadow) out
+    for (int64_t j = base + 4 * threadIdx.x; j < end; j += 4 * 256) {
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(t.g + j);
+      f32x4 p4 = *reinterpret_cast<const f32x4*>(t.p + j);
+      f32x4 m4 = *reinterpret_cast<const f32x4*>(t.m + j);
+      f32x4 v4 = *reinterpret_cast<const f32x4*>(t.v + j);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float p = p4[k], m = m4[k], v = v4[k];
+        update(g4[k], p, m, v);
+        p4[k] = p; m4[k] = m; v4[k] = v;
       }
-      if (t.shadow_dtype == PTV3_BF16) {
-        reinterpret_cast<__bf16*>(t.shadow)[j] = (__bf16)p;
-        if (t.shadow_t) reinterpret_cast<__bf16*>(t.shadow_t)[jt] = (__bf16)p;
-      } else {
-        reinterpret_cast<float*>(t.shadow)[j] = p;
-        if (t.shadow_t) reinterpret_cast<float*>(t.shadow_t)[jt] = p;
+      *reinterpret_cast<f32x4*>(t.p + j) = p4;
+      *reinterpret_cast<f32x4*>(t.m + j) = m4;
+      *reinterpret_cast<f32x4*>(t.v + j) = v4;
+      if (t.shadow) {
+        if (t.shadow_dtype == PTV3_BF16)
+          *reinterpret_cast<s16x4*>(reinterpret_cast<__bf16*>(t.shadow) + j) = pack4<__bf16>(p4[0], p4[1], p4[2], p4[3]);
+        else
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(t.shadow) + j) = p4;
       }
     }
+    return;
+  }
+  for (int64_t j = base + threadIdx.x; j < end; j += 256) {
+    float p = t.p[j], m = t.m[j], v = t.v[j];
+    update(t.g[j], p, m, v);
+    t.p[j] = p; t.m[j] = m; t.v[j] = v;
+    if (t.shadow) {
+      if (t.shadow_dtype == PTV3_BF16) reinterpret_cast<__bf16*>(t.shadow)[j] = (__bf16)p;
+      else reinterpret_cast<float*>(t.shadow)[j] = p;
+    }
+  }
+}
+
+// shadow_t[(c * kvol + (kvol - 1 - d)) * rows + o] = shadow[(o * kvol + d) * cols + c]: the transposed (mirrored-tap)
+// copy of every weight as its own pass of 64 x 64 tiles through LDS.  Written element by element from the update
+// kernel the transposed copy was 46 M two-byte stores a whole weight row apart (each its own cache line; 1.0 ms of the
+// step for 1.4 GB of streams); tiled, both sides move 128-byte row segments.
+constexpr int SHT = 64;
+template <typename E>
+__global__ void __launch_bounds__(256) shadow_transpose_kernel(const AdamWTensor* __restrict__ tab, int ntensors) {
+  __shared__ E tile[SHT][SHT + 2];
+  int lo = 0, hi = ntensors - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const AdamWTensor t = tab[lo];
+  if (!t.shadow_t) return;   // cannot happen for a consistent table
+  const int tiles_o = (t.rows + SHT - 1) / SHT, tiles_c = (t.cols + SHT - 1) / SHT;
+  int tl = (int)blockIdx.x - t.first_tile;
+  const int tc = tl % tiles_c; tl /= tiles_c;
+  const int to = tl % tiles_o;
+  const int d = tl / tiles_o;
+  const E* __restrict__ src = reinterpret_cast<const E*>(t.shadow);
+  E* __restrict__ dst = reinterpret_cast<E*>(t.shadow_t);
+  const int x = threadIdx.x & 63, y0 = threadIdx.x >> 6;
+  for (int y = y0; y < SHT; y += 4) {          // rows o of the tile, lanes along c
+    const int o = to * SHT + y, c = tc * SHT + x;
+    if (o < t.rows && c < t.cols) tile[y][x] = src[((int64_t)o * t.kvol + d) * t.cols + c];
+  }
+  __syncthreads();
+  for (int y = y0; y < SHT; y += 4) {          // rows c of the tile, lanes along o
+    const int c = tc * SHT + y, o = to * SHT + x;
+    if (o < t.rows && c < t.cols) dst[((int64_t)c * t.kvol + (t.kvol - 1 - d)) * t.rows + o] = tile[x][y];
   }
 }
 
@@ -132,13 +186,23 @@ extern "C" int ptv3_adamw_fill_entry(void* entry_host, void* param, const void* 
   e->p = (float*)param; e->g = (const float*)grad; e->m = (float*)exp_avg; e->v = (float*)exp_avg_sq;
   e->numel = numel; e->group = group; e->first_block = first_block;
   e->shadow = nullptr; e->shadow_t = nullptr; e->rows = e->cols = e->kvol = 0; e->shadow_dtype = PTV3_F32;
-  e->step_lag = 0; e->reserved = 0;
+  e->step_lag = 0; e->first_tile = 0;
   return PTV3_OK;
 }
 
 extern "C" int ptv3_adamw_fill_step_lag(void* entry_host, int64_t step_lag) {
   PTV3_REQUIRE(step_lag >= 0 && step_lag < (1ll << 31), "adamw: step_lag %lld outside [0, 2^31)", (long long)step_lag);
   ((AdamWTensor*)entry_host)->step_lag = (int32_t)step_lag;
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_adamw_shadow_tiles(int rows, int cols, int kvol) {
+  return kvol * ((rows + SHT - 1) / SHT) * ((cols + SHT - 1) / SHT);
+}
+
+extern "C" int ptv3_adamw_fill_first_tile(void* entry_host, int first_tile) {
+  PTV3_REQUIRE(first_tile >= 0, "adamw: first_tile %d", first_tile);
+  ((AdamWTensor*)entry_host)->first_tile = first_tile;
   return PTV3_OK;
 }
 
@@ -180,7 +244,7 @@ static int adamw_runs(int ntensors, int total_blocks, const int32_t* first_block
 extern "C" int ptv3_adamw_step(const void* table_dev, int ntensors, int total_blocks, const float* lr_host,
                                const float* wd_host, int ngroups, float beta1, float beta2, float eps, int64_t step,
                                float grad_scale, const int32_t* first_block_host, const void* const* grads_host,
-                               void* stream) {
+                               int total_tiles, int shadow_dtype, void* stream) {
   PTV3_REQUIRE(ngroups >= 1 && ngroups <= 8, "adamw: ngroups %d outside [1,8]", ngroups);
   PTV3_REQUIRE(step >= 1, "adamw: step must be >= 1");
   if (ntensors == 0 || total_blocks == 0) return PTV3_OK;
@@ -200,6 +264,12 @@ extern "C" int ptv3_adamw_step(const void* table_dev, int ntensors, int total_bl
                          eps, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale, (float)step);
   });
   if (rc != PTV3_OK) return rc;
+  if (total_tiles > 0) {
+    if (shadow_dtype == PTV3_BF16)
+      hipLaunchKernelGGL(shadow_transpose_kernel<short>, dim3((unsigned)total_tiles), dim3(256), 0, s, tab, ntensors);
+    else
+      hipLaunchKernelGGL(shadow_transpose_kernel<float>, dim3((unsigned)total_tiles), dim3(256), 0, s, tab, ntensors);
+  }
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

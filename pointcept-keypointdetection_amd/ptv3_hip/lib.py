@@ -99,7 +99,10 @@ SIGNATURES = {
     "ptv3_adamw_fill_entry": (c_int, [P, P, P, P, P, c_int64, c_int, c_int]),
     "ptv3_adamw_fill_shadow": (c_int, [P, P, P, c_int, c_int, c_int, c_int]),
     "ptv3_adamw_fill_step_lag": (c_int, [P, c_int64]),
-    "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P, P, P]),
+    "ptv3_adamw_step": (c_int, [P, c_int, c_int, P, P, c_int, c_float, c_float, c_float, c_int64, c_float, P, P, c_int,
+                                c_int, P]),
+    "ptv3_adamw_shadow_tiles": (c_int, [c_int, c_int, c_int]),
+    "ptv3_adamw_fill_first_tile": (c_int, [P, c_int]),
     "ptv3_grad_sqnorm": (c_int, [P, c_int, c_int, P, P, P, P, P]),
     "ptv3_grid_hash": (c_int, [P, c_int64, c_double, c_int, P, P, P, P]),
     "ptv3_keypoint_aggregate": (c_int, [P, P, P, c_int, c_int, P, P, c_int, c_float, P, P, P]),

@@ -100,7 +100,7 @@ class FusedAdamW(torch.optim.Optimizer):
         active = []
         host = ctypes.create_string_buffer(max(1, esz * len(ent)))
         base = ctypes.addressof(host)
-        blocks = 0
+        blocks = tiles = 0
         first = []
         for i, (p, st, gi) in enumerate(ent):
             first.append(blocks)
@@ -112,16 +112,19 @@ class FusedAdamW(torch.optim.Optimizer):
             if self._steps != own:
                 lib.check(lib.ptv3_adamw_fill_step_lag(base + i * esz, self._steps - own), "ptv3_adamw_fill_step_lag")
             sh = shadows[i]
+            lib.check(lib.ptv3_adamw_fill_first_tile(base + i * esz, tiles), "ptv3_adamw_fill_first_tile")
             if sh is not None:
                 rows, cols, kvol = sh["dims"]
                 lib.check(lib.ptv3_adamw_fill_shadow(base + i * esz, sh["nat"].data_ptr(), sh["t"].data_ptr(), rows,
                                                      cols, kvol, 0 if self.shadow_dtype == torch.float32 else 1),
                           "ptv3_adamw_fill_shadow")
+                tiles += lib.ptv3_adamw_shadow_tiles(rows, cols, kvol)
             blocks += (p.numel() + chunk - 1) // chunk
         dev = ent[0][0].device if ent else torch.device("cuda")
         self._table = torch.frombuffer(host, dtype=torch.uint8).clone().to(dev)
         self._partial = torch.empty(max(blocks, 1), dtype=torch.float32, device=dev)
         self._first_blocks = (ctypes.c_int32 * max(1, len(first)))(*first)
+        self._tiles = tiles
         self._nt, self._nb, self._key, self._active = len(ent), blocks, key, active
 
     def _sync_steps(self):
@@ -170,7 +173,9 @@ class FusedAdamW(torch.optim.Optimizer):
         b1, b2 = self.param_groups[0]["betas"]
         lib.check(lib.ptv3_adamw_step(self._table.data_ptr(), self._nt, self._nb, lr, wd, ng, float(b1), float(b2),
                                       float(self.param_groups[0]["eps"]), self._steps, float(grad_scale),
-                                      self._first_blocks, self._grad_ptrs, _stream()), "ptv3_adamw_step")
+                                      self._first_blocks, self._grad_ptrs, self._tiles,
+                                      0 if self.shadow_dtype in (None, torch.float32) else 1, _stream()),
+                  "ptv3_adamw_step")
         # The kernel wrote the parameters through raw pointers: tell torch.  Every eval-side cache (folded BatchNorm,
         # cast / permuted weights, the executor's packed table) is keyed on (data_ptr, _version); without the bump an
         # evaluation between two training epochs would keep running on the weights of the first one.
