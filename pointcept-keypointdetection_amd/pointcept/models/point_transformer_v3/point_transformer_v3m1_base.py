@@ -411,10 +411,65 @@ class SerializedPooling(PointModule):
         self.norm = PointSequential(norm_layer(out_channels)) if norm_layer is not None else None
         self.act = PointSequential(act_layer()) if act_layer is not None else None
 
-    def forward(self, point: Point):
+    def _pooling_depth(self, serialized_depth):
         pooling_depth = (math.ceil(self.stride) - 1).bit_length()
-        if pooling_depth > point.serialized_depth:
-            pooling_depth = 0
+        return 0 if pooling_depth > serialized_depth else pooling_depth
+
+    def plan_geometry(self, geo):
+        """Everything of this stage that depends on coordinates only: clusters, the pooled coordinates / codes and
+        their serialized order.  `geo`: mapping with serialized_code / _order / _depth, grid_coord, batch, offset,
+        optionally coord.  A training forward computes the plans of ALL stages before the first feature kernel
+        (PointTransformerV3._plan_pooling): the host sync inside pool_segments then meets a near-empty queue instead of
+        draining the feature pipeline once per stage.  Draws the order shuffle (:408-412) - same CPU RNG sequence as
+        computing the stages one after the other."""
+        depth_in = geo["serialized_depth"]
+        pooling_depth = self._pooling_depth(depth_in)
+        code = geo["serialized_code"]
+        order0 = geo["serialized_order"][0]
+        nb = len(geo["offset"])
+        batch = geo["batch"].long().contiguous()
+        cluster, seg_start, n_out, pooled_offset, pooled_offset_host = ops.pool_segments(
+            code[0], order0, pooling_depth * 3, batch=batch, num_scenes=nb)
+        perm = torch.randperm(code.shape[0]).tolist() if self.shuffle_orders else None
+        coord, grid_coord, batch_out, code_out = ops.pool_geometry(
+            geo["coord"].float().contiguous() if geo.get("coord") is not None else None,
+            geo["grid_coord"].long().contiguous(), batch, code, order0, seg_start, n_out, pooling_depth, row_perm=perm)
+        depth = depth_in - pooling_depth
+        end_bit = max(1, depth * 3 + max(nb - 1, 0).bit_length())
+        order, inverse = ops.argsort_codes(code_out, end_bit)
+        return dict(cluster=cluster, seg_start=seg_start, n_out=n_out, order0=order0, pooling_depth=pooling_depth,
+                    child=dict(coord=coord, grid_coord=grid_coord, batch=batch_out, serialized_code=code_out,
+                               serialized_order=order, serialized_inverse=inverse, serialized_depth=depth,
+                               offset=pooled_offset, _offset_host=pooled_offset_host))
+
+    def _forward_planned(self, point: Point, plans):
+        """Training forward on a precomputed geometry plan: projection, taped segment max, norm / act."""
+        plan, child = plans[0], plans[0]["child"]
+        feat = A.segment_max(self.proj(point.feat), plan["order0"], plan["seg_start"], plan["n_out"])
+        point_dict = Point(feat=feat, **{k: v for k, v in child.items() if v is not None})
+        if "_grid_max_host" in point.keys():
+            point_dict["_grid_max_host"] = [g >> plan["pooling_depth"] for g in point["_grid_max_host"]]
+        for key in ("condition", "context"):
+            if key in point.keys():
+                point_dict[key] = point[key]
+        if self.traceable:
+            point_dict["pooling_inverse"] = plan["cluster"]
+            point_dict["pooling_parent"] = point
+            point_dict["_pool_segments"] = (plan["order0"], plan["seg_start"])
+        if len(plans) > 1:
+            point_dict["_pool_plans"] = plans[1:]
+        point = point_dict
+        if self.norm is not None:
+            point = self.norm(point)
+        if self.act is not None:
+            point = self.act(point)
+        point.sparsify()
+        return point
+
+    def forward(self, point: Point):
+        if self.training and "_pool_plans" in point.keys():
+            return self._forward_planned(point, point.pop("_pool_plans"))
+        pooling_depth = self._pooling_depth(point.serialized_depth)
         assert {"serialized_code", "serialized_order", "serialized_inverse", "serialized_depth"}.issubset(
             point.keys()), "Run point.serialization() point cloud before SerializedPooling"
         code = point.serialized_code
@@ -695,6 +750,19 @@ class PointTransformerV3(PointModule):
             return torch.bfloat16 if dt in (torch.bfloat16, torch.float16) else torch.float32
         return torch.float32
 
+    def _plan_pooling(self, point):
+        """geometry of every pooling stage of the encoder, chained, before any feature kernel is queued"""
+        pools = [m for m in self.enc.modules() if isinstance(m, SerializedPooling)]
+        geo = {k: point[k] for k in ("serialized_code", "serialized_order", "serialized_depth", "grid_coord", "batch",
+                                     "offset")}
+        geo["coord"] = point["coord"] if "coord" in point.keys() else None
+        plans = []
+        for m in pools:
+            plans.append(m.plan_geometry(geo))
+            geo = plans[-1]["child"]
+        if plans:
+            point["_pool_plans"] = plans
+
     def forward(self, data_dict, _head=None):
         check_sync_batchnorm(self)  # sync_bn=True: torch converted the BatchNorm1d modules, take them back
         # eval: no autograd tape (fused kernels / native executor); train: one taped Function per layer
@@ -720,6 +788,8 @@ class PointTransformerV3(PointModule):
                     point["_head_out"] = head_out
                 return point
             point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
+            if self.training:
+                self._plan_pooling(point)
             point.sparsify()
             point = self.embedding(point)
             point = self.enc(point)

@@ -457,6 +457,29 @@ def pool_reduce(feat, coord, grid_coord, batch, code, order0, seg_start, n_out, 
     return feat_out, coord_out, grid_out, batch_out, code_out
 
 
+def pool_geometry(coord, grid_coord, batch, code, order0, seg_start, n_out, pooling_depth, row_perm=None):
+    """The geometry half of ptv3_pool_reduce alone (no feature matrix): coord mean, grid >> depth, batch and the
+    pooled codes of every cluster - what a training forward can compute for ALL pooling stages before the first
+    feature kernel (the host syncs of pool_segments then fall on a near-empty queue)."""
+    _chk(coord, "coord", torch.float32, 2)
+    _chk(grid_coord, "grid_coord", torch.int64, 2)
+    _chk(batch, "batch", torch.int64, 1)
+    _chk(code, "code", torch.int64, 2)
+    _chk(order0, "order0", torch.int64, 1)
+    _chk(seg_start, "seg_start", torch.int32, 1)
+    k, n = code.shape
+    dev = code.device
+    coord_out = torch.empty((n_out, 3), dtype=torch.float32, device=dev) if coord is not None else None
+    grid_out = torch.empty((n_out, 3), dtype=torch.int64, device=dev)
+    batch_out = torch.empty(n_out, dtype=torch.int64, device=dev)
+    code_out = torch.empty((k, n_out), dtype=torch.int64, device=dev)
+    lib.check(lib.ptv3_pool_reduce(None, _p(coord), _p(grid_coord), _p(batch), _p(code), k, _p(order0), _p(seg_start), n,
+                                   n_out, 4, int(pooling_depth), None, None, ACT_NONE,
+                                   (ctypes.c_int * k)(*row_perm) if row_perm is not None else None, None, _p(coord_out),
+                                   _p(grid_out), _p(batch_out), _p(code_out), PTV3_F32, _stream()), "ptv3_pool_reduce")
+    return coord_out, grid_out, batch_out, code_out
+
+
 # ---------------------------------------------------------------------------------------------
 # training: backward kernels
 # ---------------------------------------------------------------------------------------------
