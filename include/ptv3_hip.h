@@ -383,21 +383,22 @@ int ptv3_window_attn_rpe_bwd(const void* qkv, const void* out, const void* dout,
  *   out = f2 + mask2 * fc2(GELU(fc1(LN2(f2))))
  * All (n, .) tensors in `dtype`, vectors / gradients of parameters fp32.  w_*: (cout, K) as ptv3_gemm's w; wt_*
  * (backward): W^T (cin, cout) of the linears, the mirrored-tap transposed weight (cin, kvol*cout) of the conv.
- * conv_feat NULL: the xCPE conv reads feat (every block but the first decoder block of a stage).  mask1 / mask2 (n) in
- * dtype or NULL: per-point DropPath factors.  cu_seqlens NULL: uniform windows of `patch` slots.
+ * conv_feat NULL: the xCPE conv reads feat (every block but the first decoder block of a stage).  mask1 / mask2 (n) fp32
+ * or NULL: uniform draws u; the per-point DropPath factor of a branch is u[i] < keep ? 1 / keep : 0 (timm drop_path with
+ * scale_by_keep on the (N, C) matrix).  cu_seqlens NULL: uniform windows of `patch` slots.
  * fwd writes c1 .. out; bwd reads them plus dout and writes dfeat (and dconv_feat), dw_* (cout, K), db_* (cout),
  * dln0/1/2 (2, c) = [dgamma | dbeta] of the three LayerNorms.  workspace: ptv3_block_train_workspace_bytes(). */
 typedef struct ptv3_block_train {
   int64_t n, n_pad;
   int32_t c, hidden, heads, patch, kvol, num_windows, dtype, reserved;
-  float scale, eps;
+  float scale, eps, keep1, keep2;
   double sum_len_sq;
   const int32_t *nbr, *row_order, *win_order, *win_inverse, *cu_seqlens;
   const void *feat, *conv_feat;
   const void *w_conv, *w_lin, *w_qkv, *w_proj, *w_fc1, *w_fc2;
   const void *wt_conv, *wt_lin, *wt_qkv, *wt_proj, *wt_fc1, *wt_fc2;
   const float *b_conv, *b_lin, *b_qkv, *b_proj, *b_fc1, *b_fc2, *g0, *b0, *g1, *b1, *g2, *b2;
-  const void *mask1, *mask2;
+  const float *mask1, *mask2;
   void *c1, *c2, *f1, *t3, *qkv, *a, *f2, *t5, *h0, *h, *out;
   const void* dout;
   void *dfeat, *dconv_feat;

@@ -14,15 +14,16 @@
 
 namespace ptv3 {
 
-// out[i][:] = (skip ? skip[i][:] : 0) + mask[i] * x[i][:]     (DropPath factor per point; fp32 fma, one rounding)
+// out[i][:] = (skip ? skip[i][:] : 0) + f[i] * x[i][:], f[i] = u[i] < keep ? 1 / keep : 0: timm's DropPath on an (N, C)
+// matrix (a Bernoulli(keep) factor per point, scaled by 1 / keep) from a uniform draw u; fp32 fma, one rounding
 template <typename T>
-__global__ void __launch_bounds__(256) rowscale_add_kernel(const T* __restrict__ x, const T* __restrict__ mask,
-                                                           const T* __restrict__ skip, T* __restrict__ out,
-                                                           int64_t total4, int c4) {
+__global__ void __launch_bounds__(256) rowscale_add_kernel(const T* __restrict__ x, const float* __restrict__ u,
+                                                           float keep, float inv_keep, const T* __restrict__ skip,
+                                                           T* __restrict__ out, int64_t total4, int c4) {
   typedef typename Vec4<T>::type V4;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total4) return;
-  const float f = to_f32<T>(mask[i / c4]);
+  const float f = u[i / c4] < keep ? inv_keep : 0.f;
   float xv[4], sv[4] = {0.f, 0.f, 0.f, 0.f};
   unpack4<T>(reinterpret_cast<const V4*>(x)[i], xv);
   if (skip) unpack4<T>(reinterpret_cast<const V4*>(skip)[i], sv);
@@ -30,16 +31,17 @@ __global__ void __launch_bounds__(256) rowscale_add_kernel(const T* __restrict__
                                            fmaf(f, xv[3], sv[3]));
 }
 
-static int rowscale_add(const void* x, const void* mask, const void* skip, void* out, int64_t m, int c, int dtype,
-                        hipStream_t s) {
+static int rowscale_add(const void* x, const float* u, float keep, const void* skip, void* out, int64_t m, int c,
+                        int dtype, hipStream_t s) {
+  const float inv_keep = keep > 0.f ? 1.0f / keep : 0.f;
   const int64_t total4 = m * c / 4;
   if (total4 == 0) return PTV3_OK;
   dim3 grid((unsigned)cdiv(total4, 256));
   if (dtype == PTV3_F32)
-    hipLaunchKernelGGL(rowscale_add_kernel<float>, grid, dim3(256), 0, s, (const float*)x, (const float*)mask,
+    hipLaunchKernelGGL(rowscale_add_kernel<float>, grid, dim3(256), 0, s, (const float*)x, u, keep, inv_keep,
                        (const float*)skip, (float*)out, total4, c / 4);
   else
-    hipLaunchKernelGGL(rowscale_add_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, (const __bf16*)mask,
+    hipLaunchKernelGGL(rowscale_add_kernel<__bf16>, grid, dim3(256), 0, s, (const __bf16*)x, u, keep, inv_keep,
                        (const __bf16*)skip, (__bf16*)out, total4, c / 4);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
@@ -140,7 +142,7 @@ extern "C" int ptv3_block_train_fwd(const ptv3_block_train* b, void* stream) {
   if (b->mask1) {
     TRY(ptv3_gemm(b->a, b->w_proj, tmp, n, c, c, 1, nullptr, nullptr, b->b_proj, nullptr, nullptr, PTV3_ACT_NONE,
                   nullptr, nullptr, nullptr, dt, scratch, sb, s));
-    TRY(rowscale_add(tmp, b->mask1, b->f1, b->f2, n, c, dt, s));
+    TRY(rowscale_add(tmp, b->mask1, b->keep1, b->f1, b->f2, n, c, dt, s));
   } else {
     TRY(ptv3_gemm(b->a, b->w_proj, b->f2, n, c, c, 1, nullptr, nullptr, b->b_proj, nullptr, nullptr, PTV3_ACT_NONE,
                   b->f1, nullptr, nullptr, dt, scratch, sb, s));
@@ -152,7 +154,7 @@ extern "C" int ptv3_block_train_fwd(const ptv3_block_train* b, void* stream) {
   if (b->mask2) {
     TRY(ptv3_gemm(b->h, b->w_fc2, tmp, n, hd, c, 1, nullptr, nullptr, b->b_fc2, nullptr, nullptr, PTV3_ACT_NONE,
                   nullptr, nullptr, nullptr, dt, scratch, sb, s));
-    TRY(rowscale_add(tmp, b->mask2, b->f2, b->out, n, c, dt, s));
+    TRY(rowscale_add(tmp, b->mask2, b->keep2, b->f2, b->out, n, c, dt, s));
   } else {
     TRY(ptv3_gemm(b->h, b->w_fc2, b->out, n, hd, c, 1, nullptr, nullptr, b->b_fc2, nullptr, nullptr, PTV3_ACT_NONE,
                   b->f2, nullptr, nullptr, dt, scratch, sb, s));
@@ -196,7 +198,7 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   TRY(ptv3_gemm_tn(dy, x, nullptr, dw, db, n, cout, cin, 1, dt, scratch, sb, s))
   // ---- MLP branch
   const void* dmp = b->dout;
-  if (b->mask2) { TRY(rowscale_add(b->dout, b->mask2, nullptr, dm, n, c, dt, s)); dmp = dm; }
+  if (b->mask2) { TRY(rowscale_add(b->dout, b->mask2, b->keep2, nullptr, dm, n, c, dt, s)); dmp = dm; }
   GEMM(dmp, b->wt_fc2, dh, c, hd);
   GEMM_TN(dmp, b->h, b->dw_fc2, b->db_fc2, c, hd);
   TRY(ptv3_act_bwd(dh, b->h0, nullptr, nullptr, PTV3_ACT_GELU, dh, n, hd, dt, s));            // dh0 in place
@@ -205,7 +207,7 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   TRY(ptv3_layernorm_bwd(b->f2, dt5, b->dout, b->g2, b->eps, df2, b->dln2, n, c, dt, scratch, sb, s));
   // ---- attention branch
   const void* dpp = df2;
-  if (b->mask1) { TRY(rowscale_add(df2, b->mask1, nullptr, dp, n, c, dt, s)); dpp = dp; }
+  if (b->mask1) { TRY(rowscale_add(df2, b->mask1, b->keep1, nullptr, dp, n, c, dt, s)); dpp = dp; }
   GEMM(dpp, b->wt_proj, da, c, c);
   GEMM_TN(dpp, b->a, b->dw_proj, b->db_proj, c, c);
   if (b->cu_seqlens)

@@ -298,16 +298,22 @@ class Block(PointModule):
                 and self.cpe[2].eps == self.norm1[0].eps == self.norm2[0].eps
                 and isinstance(self.drop_path[0], (DropPath, nn.Identity)))
 
-    def _drop_mask(self, feat):
-        """per-point DropPath factor (timm drop_path on the (N, C) matrix), or None"""
+    def _drop_draw(self, point):
+        """(uniform draw per point (fp32), keep probability) of one DropPath, or None.  The draws of a level come from one
+        torch.rand pool on the Point (16 rows at a time): one launch per eight blocks instead of three per DropPath; the
+        factor u < keep ? 1 / keep : 0 (timm drop_path, scale_by_keep) is formed inside the block kernels."""
         dp = self.drop_path[0]
         if not isinstance(dp, DropPath) or dp.drop_prob == 0.0:
             return None
-        keep = 1.0 - dp.drop_prob
-        mask = feat.new_empty((feat.shape[0], 1)).bernoulli_(keep)
-        if keep > 0.0 and dp.scale_by_keep:
-            mask.div_(keep)
-        return mask
+        if not dp.scale_by_keep:
+            raise NotImplementedError("DropPath(scale_by_keep=False) on the fused training path")
+        pool = point.get("_drop_pool")
+        if pool is None or pool[1] >= pool[0].shape[0]:
+            pool = [torch.rand((16, point.feat.shape[0]), dtype=torch.float32, device=point.feat.device), 0]
+            point["_drop_pool"] = pool
+        row = pool[0][pool[1]]
+        pool[1] += 1
+        return row, 1.0 - dp.drop_prob
 
     def _forward_train(self, point: Point):
         """Training: the whole block as ONE taped Function (ptv3_hip.autograd.BlockFn) - same kernels and statement
@@ -323,8 +329,8 @@ class Block(PointModule):
                   self.attn.proj.weight, self.attn.proj.bias, self.norm2[0].weight, self.norm2[0].bias,
                   mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)
         # the two DropPath draws in the reference's order: attention branch, then MLP branch
-        mask1 = self._drop_mask(feat)
-        mask2 = self._drop_mask(feat)
+        mask1 = self._drop_draw(point)
+        mask2 = self._drop_draw(point)
         out = A.block(feat, conv_feat, params, spt.neighbors(3, self.cpe[0].indice_key), spt.row_order, wo, wi,
                       self.attn.num_heads, K, self.attn.scale, mask1, mask2, self.cpe[2].eps,
                       self.attn.window_cu(point))

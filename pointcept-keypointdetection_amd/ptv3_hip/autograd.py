@@ -477,7 +477,7 @@ class BlockNativeFn(Function):
     @staticmethod
     def forward(ctx, feat, conv_feat, conv_w, conv_b, lin_w, lin_b, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b,
                 proj_w, proj_b, n2_g, n2_b, fc1_w, fc1_b, fc2_w, fc2_b, nbr, row_order, wo, wi, heads, patch, scale,
-                mask1, mask2, eps, cu=None):
+                mask1, mask2, eps, cu=None, keep1=1.0, keep2=1.0):
         from .lib import BlockTrain
         dt = feat.dtype
         feat = feat.contiguous()
@@ -501,7 +501,10 @@ class BlockNativeFn(Function):
                         ("b_fc2", fc2_b), ("g0", ln0_g), ("b0", ln0_b), ("g1", n1_g), ("b1", n1_b), ("g2", n2_g),
                         ("b2", n2_b)):
             setattr(b, name, _f32_ptr(p, name))
-        b.mask1, b.mask2 = _ptr(mask1), _ptr(mask2)
+        for name, u in (("mask1", mask1), ("mask2", mask2)):    # uniform draws per point (fp32), see drop_factor
+            if u is not None and (u.dtype != torch.float32 or u.numel() != n or not u.is_contiguous()):
+                raise TypeError(f"BlockNativeFn: {name} must be a contiguous fp32 draw per point")
+        b.mask1, b.mask2, b.keep1, b.keep2 = _ptr(mask1), _ptr(mask2), float(keep1), float(keep2)
         # activations the backward needs: one allocation, carved into (n, c) x 9, (n, 3c), (n, hidden) x 2
         flat = torch.empty(n * (9 * c + 3 * c + 2 * hidden), dtype=dt, device=dev)
         views, at = {}, 0
@@ -551,12 +554,27 @@ class BlockNativeFn(Function):
         return (dfeat, dconv, dw_conv.view(conv_shape), db_conv, dw_lin.view(c, c), db_lin, dln0[:c], dln0[c:], dln1[:c],
                 dln1[c:], dw_qkv.view(3 * c, c), db_qkv, dw_proj.view(c, c), db_proj, dln2[:c], dln2[c:],
                 dw_fc1.view(hidden, c), db_fc1, dw_fc2.view(c, hidden), db_fc2, None, None, None, None, None, None, None,
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 _NATIVE_BLOCK = os.environ.get("PTV3_BLOCK_NATIVE", "1") != "0"
 
 
-def block(feat, conv_feat, blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps, cu=None):
-    fn = BlockNativeFn if _NATIVE_BLOCK and blk_params[0].dtype == torch.float32 else BlockFn
-    return fn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, mask1, mask2, eps, cu)
+def drop_factor(drop, dtype):
+    """(n, 1) DropPath factor in `dtype` from a (uniform draw (n) fp32, keep probability) pair, or None"""
+    if drop is None:
+        return None
+    u, keep = drop
+    return ((u < keep).to(torch.float32) * (1.0 / keep if keep > 0.0 else 0.0)).to(dtype).unsqueeze(1)
+
+
+def block(feat, conv_feat, blk_params, nbr, row_order, wo, wi, heads, patch, scale, drop1, drop2, eps, cu=None):
+    """drop1 / drop2: None or (u, keep) - a uniform draw per point (fp32, contiguous) and the keep probability of the
+    attention / MLP branch's DropPath (factor u < keep ? 1 / keep : 0, as timm's drop_path with scale_by_keep)."""
+    if _NATIVE_BLOCK and blk_params[0].dtype == torch.float32:
+        u1, k1 = drop1 if drop1 is not None else (None, 1.0)
+        u2, k2 = drop2 if drop2 is not None else (None, 1.0)
+        return BlockNativeFn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale, u1, u2, eps,
+                                   cu, float(k1), float(k2))
+    return BlockFn.apply(feat, conv_feat, *blk_params, nbr, row_order, wo, wi, heads, patch, scale,
+                         drop_factor(drop1, feat.dtype), drop_factor(drop2, feat.dtype), eps, cu)

@@ -21,7 +21,7 @@ class BlockTrain(ctypes.Structure):
     """struct ptv3_block_train of include/ptv3_hip.h (field for field)"""
     _fields_ = ([("n", c_int64), ("n_pad", c_int64)] +
                 [(k, ctypes.c_int32) for k in ("c", "hidden", "heads", "patch", "kvol", "num_windows", "dtype", "reserved")] +
-                [("scale", c_float), ("eps", c_float), ("sum_len_sq", c_double)] +
+                [("scale", c_float), ("eps", c_float), ("keep1", c_float), ("keep2", c_float), ("sum_len_sq", c_double)] +
                 [(k, P) for k in ("nbr", "row_order", "win_order", "win_inverse", "cu_seqlens", "feat", "conv_feat",
                                   "w_conv", "w_lin", "w_qkv", "w_proj", "w_fc1", "w_fc2",
                                   "wt_conv", "wt_lin", "wt_qkv", "wt_proj", "wt_fc1", "wt_fc2",

@@ -54,6 +54,7 @@ class FusedAdamW(torch.optim.Optimizer):
         # and is written back whenever the table is rebuilt or a state_dict is taken.
         self._steps = 0
         self._active = []   # (param, lag) of the current device table
+        self._fast = None   # (parameters of the table, their addresses) for the per-step fast path of _build
 
     def _entries(self):
         out = []
@@ -84,6 +85,19 @@ class FusedAdamW(torch.optim.Optimizer):
         return sh
 
     def _build(self):
+        # fast path (every step but the first): the same parameters, in the same places, all with a gradient - only the
+        # gradient addresses are new.  The full walk with its dtype / layout checks runs when anything else changed.
+        fast = self._fast
+        if fast is not None and self._key is not None:
+            params, ptrs = fast
+            try:
+                grads = [p.grad.data_ptr() for p in params]
+            except AttributeError:      # a parameter lost its gradient: rebuild
+                grads = None
+            if grads is not None and [p.data_ptr() for p in params] == ptrs and \
+                    sum(1 for g in self.param_groups for p in g["params"] if p.grad is not None) == len(params):
+                self._grad_ptrs = (ctypes.c_void_p * max(1, len(grads)))(*grads)
+                return
         ent = self._entries()
         shadows = [self._shadow(p) for p, _, _ in ent]
         # gradient addresses are NOT part of the key: they change every step after zero_grad(set_to_none=True) and
@@ -125,6 +139,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._partial = torch.empty(max(blocks, 1), dtype=torch.float32, device=dev)
         self._first_blocks = (ctypes.c_int32 * max(1, len(first)))(*first)
         self._tiles = tiles
+        self._fast = ([p for p, _, _ in ent], [p.data_ptr() for p, _, _ in ent])
         self._nt, self._nb, self._key, self._active = len(ent), blocks, key, active
 
     def _sync_steps(self):
@@ -145,7 +160,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 st["step"] = st["step"].detach().to("cpu", torch.float32)
             elif "step" in st:
                 st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
-        self._key, self._active = None, []   # moments are new tensors: rebuild the device table, re-derive the lags
+        self._key, self._active, self._fast = None, [], None   # moments are new tensors: rebuild the device table
 
     @torch.no_grad()
     def zero_grad(self, set_to_none=True):

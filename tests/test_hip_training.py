@@ -413,13 +413,14 @@ def test_fused_adamw_state_dict_round_trip_with_torch_adamw(dev):
 
 
 @pytest.mark.parametrize("dtype,drop_path,flash", [(torch.float32, 0.0, False), (torch.bfloat16, 0.0, True),
-                                                   (torch.bfloat16, 0.3, False)])
+                                                   (torch.float32, 0.3, False)])
 def test_native_block_calls_equal_the_per_op_composition(dev, dtype, drop_path, flash):
     """ptv3_block_train_fwd / _bwd (one native call per block and direction) against BlockFn, the same block composed
     from the per-op entry points: identical kernels in identical order, so loss and every gradient are bitwise equal
-    without DropPath; with DropPath the factor is applied by one fused multiply-add here and by torch.addcmul there
-    (one bf16 rounding apart at most).  Covers uniform and ragged (enable_flash) windows and the first decoder block,
-    whose conv reads the skip tensor."""
+    without DropPath; with DropPath both paths form the factor from the SAME uniform draws (u < keep ? 1 / keep : 0),
+    the native one inside a fused multiply-add, the composition as a tensor fed to torch.addcmul: fp32 results agree to
+    rounding.  Covers uniform and ragged (enable_flash) windows and the first decoder block, whose conv reads the
+    skip tensor."""
     import ptv3_scenes as S
     from ptv3_hip import autograd as A
     cfg = dict(TINY_CFG, drop_path=drop_path, enable_flash=flash)
@@ -445,7 +446,7 @@ def test_native_block_calls_equal_the_per_op_composition(dev, dtype, drop_path, 
         for n in g0:
             assert torch.equal(g1[n], g0[n]), n
     else:
-        assert abs(l1.item() - l0.item()) < 2e-2 * max(1.0, abs(l0.item()))
+        assert abs(l1.item() - l0.item()) < 1e-5 * max(1.0, abs(l0.item()))
         gmax = max(g.abs().max().item() for g in g0.values())
         for n in g0:
-            assert (g1[n] - g0[n]).abs().max().item() <= 0.05 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
+            assert (g1[n] - g0[n]).abs().max().item() <= 1e-3 * max(g0[n].abs().max().item(), 1e-2 * gmax), n
