@@ -332,8 +332,20 @@ int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, float* dw, f
  *   mode 2: out[2][c]    = sum a, sum a*(b - mu)*rs       (BatchNorm1d backward: a = dy, b = x)
  *   mode 3: out[2][c]    = sum a, sum (a - mu)^2          (centred second pass of the batch variance) */
 size_t ptv3_col_reduce_workspace_bytes(int64_t m, int c);
-int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, int mode, float* out,
+int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, float mu_scale, int mode, float* out,
                     int64_t m, int c, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+/* modes 2 and 3 subtract mu[c] * mu_scale: with mu = the column sums of a first pass and mu_scale = 1 / m the mean never
+ * exists as a tensor.
+ * The per-channel arithmetic of a BatchNorm1d training step (:439-441, 508-510, the head of offset_keypoint_ptv3.py) in one
+ * launch each.  ptv3_bn_finalize: sum / centred_sq (c) = the two col_reduce passes; writes mean, rstd, scale = weight rstd,
+ * shift = bias - mean scale and updates the running buffers (NULL: none) with `momentum` and the unbiased variance, as
+ * torch.nn.BatchNorm1d does.  ptv3_bn_bwd_coeffs: sums (2, c) = col_reduce mode 2 of the pre-activation gradient; writes
+ * the coefficients of ptv3_affine2 (dx = ca dy + cb x + cc). */
+int ptv3_bn_finalize(const float* sum, const float* centred_sq, int64_t m, const float* weight, const float* bias,
+                     float* running_mean, float* running_var, float momentum, float eps, float* mean, float* rstd,
+                     float* scale, float* shift, int c, void* stream);
+int ptv3_bn_bwd_coeffs(const float* sums, int64_t m, const float* weight, const float* rstd, const float* mean, float* ca,
+                       float* cb, float* cc, int c, void* stream);
 /* LayerNorm backward (statistics recomputed from x): dx (m, c) dtype, dgamma_dbeta (2, c) fp32.
  * add (m, c) dtype or NULL: dx = add + (input gradient) - the gradient arriving over the residual connection around the
  * normalised branch (Block.forward, :318-338), folded into the store.  workspace: ptv3_col_reduce_workspace_bytes(m, c). */

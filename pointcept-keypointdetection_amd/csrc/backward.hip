@@ -247,7 +247,8 @@ static int64_t tn_chunks(int64_t m, int cout, int cin, int kvol, int64_t* rows_p
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) col_reduce_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                           const float* __restrict__ mu, const float* __restrict__ rs,
-                                                          int64_t m, int c, int64_t rb, float* __restrict__ slab) {
+                                                          float mu_scale, int64_t m, int c, int64_t rb,
+                                                          float* __restrict__ slab) {
   constexpr int NQ = MODE == 0 ? 1 : 2;
   __shared__ float red[NQ][4][64];
   const int t = threadIdx.x & 63, rl = threadIdx.x >> 6;
@@ -256,8 +257,8 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const T* __restrict__ a
   float s0 = 0.f, s1 = 0.f;
   if (col < c) {
     float mc = 0.f, rc = 1.f;
-    if (MODE == 2) { mc = mu[col]; rc = rs[col]; }
-    if (MODE == 3) mc = mu[col];
+    if (MODE == 2) { mc = mu[col] * mu_scale; rc = rs[col]; }
+    if (MODE == 3) mc = mu[col] * mu_scale;
     for (int64_t r = r0 + rl; r < r1; r += 4) {
       const float va = to_f32<T>(a[r * c + col]);
       s0 += va;
@@ -283,6 +284,43 @@ static int64_t col_chunks(int64_t m, int64_t* rb) {
   if (r < 16) r = 16;
   *rb = r;
   return cdiv(m, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d per-channel arithmetic of a training step as ONE launch each (it was ~25 element-wise torch launches
+// over (c) vectors per BatchNorm layer and step: 350 launches of the fork model's 14 layers)
+//   finalize: mean = sum / m, var = centred_sq / m (biased), rstd, scale = gamma rstd, shift = beta - mean scale,
+//             running_mean / running_var updated in place (momentum, unbiased variance) as torch does
+//   bwd coeffs: dx = ca dy + cb x + cc  with  ca = gamma rstd, cb = -ca rstd k2, cc = ca (mean rstd k2 - k1),
+//             k1 = sum(dpre) / m, k2 = sum(dpre xhat) / m
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq, float inv_m,
+                                   float unbias, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, float momentum,
+                                   float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                   float* __restrict__ scale, float* __restrict__ shift, int c) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= c) return;
+  const float mu = sum[j] * inv_m, var = sq[j] * inv_m;
+  const float r = rsqrtf(var + eps);
+  const float sc = gamma[j] * r;
+  mean[j] = mu; rstd[j] = r; scale[j] = sc; shift[j] = beta[j] - mu * sc;
+  if (running_mean) {
+    running_mean[j] = running_mean[j] * (1.0f - momentum) + momentum * mu;
+    running_var[j] = running_var[j] * (1.0f - momentum) + momentum * (var * unbias);
+  }
+}
+
+__global__ void bn_bwd_coeffs_kernel(const float* __restrict__ sums, float inv_m, const float* __restrict__ gamma,
+                                     const float* __restrict__ rstd, const float* __restrict__ mean,
+                                     float* __restrict__ ca, float* __restrict__ cb, float* __restrict__ cc, int c) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= c) return;
+  const float k1 = sums[j] * inv_m, k2 = sums[c + j] * inv_m;
+  const float a = gamma[j] * rstd[j];
+  ca[j] = a;
+  cb[j] = -a * rstd[j] * k2;
+  cc[j] = a * (mean[j] * rstd[j] * k2 - k1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -590,8 +628,9 @@ extern "C" size_t ptv3_col_reduce_workspace_bytes(int64_t m, int c) {
   return (size_t)col_chunks(m, &rb) * 2 * c * sizeof(float);
 }
 
-extern "C" int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, int mode, float* out,
-                               int64_t m, int c, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int ptv3_col_reduce(const void* a, const void* b, const float* mu, const float* rs, float mu_scale, int mode,
+                               float* out, int64_t m, int c, int dtype, void* workspace, size_t workspace_bytes,
+                               void* stream) {
   BWD_DTYPE_CHECK("col_reduce");
   PTV3_REQUIRE(mode >= 0 && mode <= 3, "col_reduce: mode %d outside [0,3]", mode);
   PTV3_REQUIRE(mode != 3 || mu, "col_reduce: mode 3 needs mu");
@@ -608,8 +647,8 @@ extern "C" int ptv3_col_reduce(const void* a, const void* b, const float* mu, co
   PTV3_REQUIRE(workspace_bytes >= (size_t)ns * nq * c * sizeof(float), "col_reduce: workspace too small");
   dim3 grid((unsigned)ns, (unsigned)cdiv(c, 64));
 #define CR_LAUNCH(T, MODE)                                                                                     \
-  hipLaunchKernelGGL((col_reduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)a, (const T*)b, mu, rs, m, c, \
-                     rb, (float*)workspace)
+  hipLaunchKernelGGL((col_reduce_kernel<T, MODE>), grid, dim3(256), 0, s, (const T*)a, (const T*)b, mu, rs, mu_scale, \
+                     m, c, rb, (float*)workspace)
   if (dtype == PTV3_F32) {
     if (mode == 0) CR_LAUNCH(float, 0); else if (mode == 1) CR_LAUNCH(float, 1); else if (mode == 2) CR_LAUNCH(float, 2); else CR_LAUNCH(float, 3);
   } else {
@@ -721,6 +760,28 @@ extern "C" int ptv3_segment_sum(const void* dy, const int64_t* order0, const int
   else
     hipLaunchKernelGGL((segment_bwd_kernel<__bf16, false>), grid, dim3(256), 0, s, (const __bf16*)nullptr,
                        (const __bf16*)dy, order0, seg_start, n_out, c, (__bf16*)out);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_bn_finalize(const float* sum, const float* centred_sq, int64_t m, const float* weight,
+                                const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                                float* mean, float* rstd, float* scale, float* shift, int c, void* stream) {
+  PTV3_REQUIRE(m > 0 && c > 0, "bn_finalize: m=%lld c=%d", (long long)m, c);
+  PTV3_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running buffers come together");
+  const float unbias = (float)((double)m / (double)(m > 1 ? m - 1 : 1));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, sum, centred_sq,
+                     (float)(1.0 / (double)m), unbias, weight, bias, running_mean, running_var, momentum, eps, mean, rstd,
+                     scale, shift, c);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_bn_bwd_coeffs(const float* sums, int64_t m, const float* weight, const float* rstd,
+                                  const float* mean, float* ca, float* cb, float* cc, int c, void* stream) {
+  PTV3_REQUIRE(m > 0 && c > 0, "bn_bwd_coeffs: m=%lld c=%d", (long long)m, c);
+  hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((unsigned)cdiv(c, 256)), dim3(256), 0, (hipStream_t)stream, sums,
+                     (float)(1.0 / (double)m), weight, rstd, mean, ca, cb, cc, c);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

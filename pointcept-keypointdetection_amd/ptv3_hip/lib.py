@@ -80,7 +80,9 @@ SIGNATURES = {
     "ptv3_gemm_tn_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "ptv3_gemm_tn": (c_int, [P, P, P, P, P, c_int64, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "ptv3_col_reduce_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "ptv3_col_reduce": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "ptv3_col_reduce": (c_int, [P, P, P, P, c_float, c_int, P, c_int64, c_int, c_int, P, c_size_t, P]),
+    "ptv3_bn_finalize": (c_int, [P, P, c_int64, P, P, P, P, c_float, c_float, P, P, P, P, c_int, P]),
+    "ptv3_bn_bwd_coeffs": (c_int, [P, c_int64, P, P, P, P, P, P, c_int, P]),
     "ptv3_layernorm_bwd": (c_int, [P, P, P, P, c_float, P, P, c_int64, c_int, c_int, P, c_size_t, P]),
     "ptv3_act_bwd": (c_int, [P, P, P, P, c_int, P, c_int64, c_int, c_int, P]),
     "ptv3_affine2": (c_int, [P, P, P, P, P, P, c_int64, c_int, c_int, P]),

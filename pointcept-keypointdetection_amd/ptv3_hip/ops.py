@@ -510,9 +510,9 @@ def gemm_tn(dy, x, nbr=None, kvol=1, with_bias=False):
     return (dw, db) if with_bias else dw
 
 
-def col_reduce(a, b=None, mu=None, rs=None, mode=0):
+def col_reduce(a, b=None, mu=None, rs=None, mode=0, mu_scale=1.0):
     """fp32 column sums over rows: mode 0 (c) sum a; 1 (2, c) sum a, sum a^2; 2 (2, c) sum a, sum a*(b-mu)*rs;
-    3 (2, c) sum a, sum (a-mu)^2."""
+    3 (2, c) sum a, sum (a-mu)^2.  mu is multiplied by mu_scale (column sums and 1 / m instead of a mean tensor)."""
     _chk(a, "a", _F, 2)
     _chk(b, "b", a.dtype, 2)
     _chk(mu, "mu", torch.float32, 1)
@@ -521,9 +521,32 @@ def col_reduce(a, b=None, mu=None, rs=None, mode=0):
     out = torch.empty((1 if mode == 0 else 2, c), dtype=torch.float32, device=a.device)
     nb = lib.ptv3_col_reduce_workspace_bytes(m, c)
     ws = _ws(nb, a.device)
-    lib.check(lib.ptv3_col_reduce(_p(a), _p(b), _p(mu), _p(rs), int(mode), _p(out), m, c, _dt(a), _p(ws), nb,
-                                  _stream()), "ptv3_col_reduce")
+    lib.check(lib.ptv3_col_reduce(_p(a), _p(b), _p(mu), _p(rs), float(mu_scale), int(mode), _p(out), m, c, _dt(a), _p(ws),
+                                  nb, _stream()), "ptv3_col_reduce")
     return out[0] if mode == 0 else out
+
+
+def bn_finalize(total, centred_sq, m, weight, bias, running_mean, running_var, momentum, eps):
+    """-> mean, rstd, scale, shift (c) fp32 of a BatchNorm1d training forward; running buffers updated in place."""
+    for t, nm in ((total, "total"), (centred_sq, "centred_sq"), (weight, "weight"), (bias, "bias"),
+                  (running_mean, "running_mean"), (running_var, "running_var")):
+        _chk(t, nm, torch.float32, 1)
+    c = total.shape[0]
+    out = torch.empty((4, c), dtype=torch.float32, device=total.device)
+    lib.check(lib.ptv3_bn_finalize(_p(total), _p(centred_sq), int(m), _p(weight), _p(bias), _p(running_mean),
+                                   _p(running_var), float(momentum), float(eps), _p(out[0]), _p(out[1]), _p(out[2]),
+                                   _p(out[3]), c, _stream()), "ptv3_bn_finalize")
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_bwd_coeffs(sums, m, weight, rstd, mean):
+    """-> ca, cb, cc (c) fp32: BatchNorm1d input gradient dx = ca dy + cb x + cc from the two batch sums of mode 2."""
+    _chk(sums, "sums", torch.float32, 2)
+    c = sums.shape[1]
+    out = torch.empty((3, c), dtype=torch.float32, device=sums.device)
+    lib.check(lib.ptv3_bn_bwd_coeffs(_p(sums), int(m), _p(weight), _p(rstd), _p(mean), _p(out[0]), _p(out[1]), _p(out[2]),
+                                     c, _stream()), "ptv3_bn_bwd_coeffs")
+    return out[0], out[1], out[2]
 
 
 def layernorm_bwd(x, dy, gamma, eps, add=None):
