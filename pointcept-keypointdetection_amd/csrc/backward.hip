@@ -32,8 +32,60 @@ __global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__
   }
 }
 
+// Deferred reductions: a caller that issues several slab-producing kernels back to back (the native block backward:
+// six weight gradients and three LayerNorm backward passes) can collect their reductions and run them as ONE launch at
+// the end - each reduction alone is a few microseconds of work behind a full launch (242 such launches were 1.6 ms of
+// the fork model's training step).  Every deferred producer must own its slab memory until the flush.
+struct SlabSeg { const float* slab; float* out; float* out1; long long n, n0; int nslab, first_block; };
+constexpr int SLAB_SEGS = 16;
+struct SlabSegs { SlabSeg v[SLAB_SEGS]; };
+static thread_local SlabSegs* g_defer = nullptr;
+static thread_local int g_defer_count = 0, g_defer_blocks = 0;
+
+__global__ void __launch_bounds__(256) slab_sum_multi_kernel(SlabSegs segs, int nseg) {
+  __shared__ float red[16][17];
+  int k = 0;
+#pragma unroll 1
+  for (int t = 1; t < nseg; ++t)
+    if (segs.v[t].first_block <= (int)blockIdx.x) k = t;
+  const SlabSeg g = segs.v[k];
+  const int c = threadIdx.x & 15, z0 = threadIdx.x >> 4;
+  const long long j = (long long)((int)blockIdx.x - g.first_block) * 16 + c;
+  float s = 0.f;
+  if (j < g.n)
+    for (int z = z0; z < g.nslab; z += 16) s += g.slab[(long long)z * g.n + j];
+  red[z0][c] = s;
+  __syncthreads();
+  if (z0 == 0 && j < g.n) {
+    float t = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) t += red[z][c];
+    if (j < g.n0) g.out[j] = t; else g.out1[j - g.n0] = t;
+  }
+}
+
+int slab_defer_flush(hipStream_t s) {
+  if (g_defer && g_defer_count > 0)
+    hipLaunchKernelGGL(slab_sum_multi_kernel, dim3((unsigned)g_defer_blocks), dim3(256), 0, s, *g_defer, g_defer_count);
+  g_defer_count = g_defer_blocks = 0;
+  return PTV3_OK;
+}
+void slab_defer_begin(void* storage) {   // storage: sizeof(SlabSegs) bytes owned by the caller; NULL ends deferral
+  g_defer = (SlabSegs*)storage;
+  g_defer_count = g_defer_blocks = 0;
+}
+size_t slab_defer_storage_bytes() { return sizeof(SlabSegs); }
+
 static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStream_t s, int64_t n0 = -1,
                      float* out1 = nullptr) {
+  if (g_defer) {
+    if (g_defer_count == SLAB_SEGS) slab_defer_flush(s);
+    SlabSeg& g = g_defer->v[g_defer_count++];
+    g.slab = slab; g.out = out; g.out1 = out1; g.n = n; g.n0 = n0 < 0 ? n : n0; g.nslab = nslab;
+    g.first_block = g_defer_blocks;
+    g_defer_blocks += (int)cdiv(n, 16);
+    return;
+  }
   hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, s, slab, nslab, n, out,
                      n0 < 0 ? n : n0, out1);
 }

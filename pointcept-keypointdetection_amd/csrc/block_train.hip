@@ -14,6 +14,11 @@
 
 namespace ptv3 {
 
+// deferred slab reductions (backward.hip): the reductions of the calls between begin and flush run as one launch
+void slab_defer_begin(void* storage);
+int slab_defer_flush(hipStream_t s);
+size_t slab_defer_storage_bytes();
+
 // out[i][:] = (skip ? skip[i][:] : 0) + f[i] * x[i][:], f[i] = u[i] < keep ? 1 / keep : 0: timm's DropPath on an (N, C)
 // matrix (a Bernoulli(keep) factor per point, scaled by 1 / keep) from a uniform draw u; fp32 fma, one rounding
 template <typename T>
@@ -46,6 +51,8 @@ static int rowscale_add(const void* x, const float* u, float keep, const void* s
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }
+
+struct SlabSegsStorage { alignas(16) unsigned char bytes[1024]; };   // >= slab_defer_storage_bytes(), checked at use
 
 struct Bump {   // 256-byte aligned carving of the caller's workspace
   char* base; size_t size, at;
@@ -109,8 +116,13 @@ extern "C" size_t ptv3_block_train_workspace_bytes(const ptv3_block_train* b, in
   const size_t nc = (size_t)b->n * b->c * e + 256, nh = (size_t)b->n * b->hidden * e + 256;
   size_t s = op_scratch_bytes(b, backward != 0) + 256;
   if (!backward) return s + nc;                 // p / m before the DropPath factor
-  // dm, dh (reused as dh0), dt5, df2, dp, da, dqkv, dt3, df1, dc2, dc1
-  return s + nh + 9 * nc + 3 * nc;
+  // dm, dh (reused as dh0), dt5, df2, dp, da, dqkv, dt3, df1, dc2, dc1; then one slab region per deferred reduction
+  s += nh + 9 * nc + 3 * nc;
+  const int c = b->c, h = b->hidden;
+  s += ptv3_gemm_tn_workspace_bytes(b->n, c, h, 1) + ptv3_gemm_tn_workspace_bytes(b->n, h, c, 1) +
+       2 * ptv3_gemm_tn_workspace_bytes(b->n, c, c, 1) + ptv3_gemm_tn_workspace_bytes(b->n, 3 * c, c, 1) +
+       ptv3_gemm_tn_workspace_bytes(b->n, c, c, b->kvol) + 3 * ptv3_col_reduce_workspace_bytes(b->n, c) + 9 * 256;
+  return s;
 }
 
 extern "C" int ptv3_block_train_fwd(const ptv3_block_train* b, void* stream) {
@@ -189,13 +201,32 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   void* dc2 = ws.take(nc);
   void* dc1 = ws.take(nc);
   PTV3_REQUIRE(scratch && dc1, "block_train_bwd: workspace too small (%zu bytes)", b->workspace_bytes);
+  PTV3_REQUIRE(slab_defer_storage_bytes() <= sizeof(SlabSegsStorage), "block_train_bwd: slab queue storage");
   const bool same = b->conv_feat == nullptr;
   const void* xin = same ? b->feat : b->conv_feat;
 #define GEMM(x, w, out, cin, cout) \
   TRY(ptv3_gemm(x, w, out, n, cin, cout, 1, nullptr, nullptr, nullptr, nullptr, nullptr, PTV3_ACT_NONE, nullptr, nullptr, \
                 nullptr, dt, scratch, sb, s))
-#define GEMM_TN(dy, x, dw, db, cout, cin) \
-  TRY(ptv3_gemm_tn(dy, x, nullptr, dw, db, n, cout, cin, 1, dt, scratch, sb, s))
+  // the nine reductions over row chunks (six weight gradients, three LayerNorm affine gradients) are collected and run
+  // as one launch at the end: each producer gets slab memory of its own
+  SlabSegsStorage segs;
+  slab_defer_begin(&segs);
+  struct EndDefer { ~EndDefer() { slab_defer_begin(nullptr); } } end_defer;
+  auto own = [&](size_t bytes, size_t* got) { *got = bytes; return ws.take(bytes); };
+#define GEMM_TN(dy, x, dw, db, cout, cin)                                                            \
+  do {                                                                                               \
+    size_t wb__;                                                                                     \
+    void* w__ = own(ptv3_gemm_tn_workspace_bytes(n, cout, cin, 1), &wb__);                           \
+    PTV3_REQUIRE(w__ != nullptr, "block_train_bwd: workspace too small");                            \
+    TRY(ptv3_gemm_tn(dy, x, nullptr, dw, db, n, cout, cin, 1, dt, w__, wb__, s));                    \
+  } while (0)
+#define LN_BWD(x, dy, add, g, dx, dgb)                                                               \
+  do {                                                                                               \
+    size_t wb__;                                                                                     \
+    void* w__ = own(ptv3_col_reduce_workspace_bytes(n, c), &wb__);                                   \
+    PTV3_REQUIRE(w__ != nullptr, "block_train_bwd: workspace too small");                            \
+    TRY(ptv3_layernorm_bwd(x, dy, add, g, b->eps, dx, dgb, n, c, dt, w__, wb__, s));                 \
+  } while (0)
   // ---- MLP branch
   const void* dmp = b->dout;
   if (b->mask2) { TRY(rowscale_add(b->dout, b->mask2, b->keep2, nullptr, dm, n, c, dt, s)); dmp = dm; }
@@ -204,7 +235,7 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   TRY(ptv3_act_bwd(dh, b->h0, nullptr, nullptr, PTV3_ACT_GELU, dh, n, hd, dt, s));            // dh0 in place
   GEMM(dh, b->wt_fc1, dt5, hd, c);
   GEMM_TN(dh, b->t5, b->dw_fc1, b->db_fc1, hd, c);
-  TRY(ptv3_layernorm_bwd(b->f2, dt5, b->dout, b->g2, b->eps, df2, b->dln2, n, c, dt, scratch, sb, s));
+  LN_BWD(b->f2, dt5, b->dout, b->g2, df2, b->dln2);
   // ---- attention branch
   const void* dpp = df2;
   if (b->mask1) { TRY(rowscale_add(df2, b->mask1, b->keep1, nullptr, dp, n, c, dt, s)); dpp = dp; }
@@ -220,16 +251,24 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   GEMM_TN(dqkv, b->t3, b->dw_qkv, b->db_qkv, 3 * c, c);
   // df1: the block's gradient with respect to feat when the conv reads another tensor, an intermediate otherwise
   void* df1_out = same ? df1 : b->dfeat;
-  TRY(ptv3_layernorm_bwd(b->f1, dt3, df2, b->g1, b->eps, df1_out, b->dln1, n, c, dt, scratch, sb, s));
+  LN_BWD(b->f1, dt3, df2, b->g1, df1_out, b->dln1);
   // ---- xCPE branch
-  TRY(ptv3_layernorm_bwd(b->c2, df1_out, nullptr, b->g0, b->eps, dc2, b->dln0, n, c, dt, scratch, sb, s));
+  LN_BWD(b->c2, df1_out, nullptr, b->g0, dc2, b->dln0);
   GEMM(dc2, b->wt_lin, dc1, c, c);
   GEMM_TN(dc2, b->c1, b->dw_lin, b->db_lin, c, c);
   // conv input gradient = the forward kernel on mirrored, transposed taps; lands on df1 when the conv read feat
   TRY(ptv3_gemm(dc1, b->wt_conv, same ? b->dfeat : b->dconv_feat, n, c, c, b->kvol, b->nbr, b->row_order, nullptr,
                 nullptr, nullptr, PTV3_ACT_NONE, same ? df1 : nullptr, nullptr, nullptr, dt, scratch, sb, s));
-  TRY(ptv3_gemm_tn(dc1, xin, b->nbr, b->dw_conv, b->db_conv, n, c, c, b->kvol, dt, scratch, sb, s));
+  {
+    size_t wb;
+    void* w = own(ptv3_gemm_tn_workspace_bytes(n, c, c, b->kvol), &wb);
+    PTV3_REQUIRE(w != nullptr, "block_train_bwd: workspace too small");
+    TRY(ptv3_gemm_tn(dc1, xin, b->nbr, b->dw_conv, b->db_conv, n, c, c, b->kvol, dt, w, wb, s));
+  }
+  TRY(slab_defer_flush(s));
 #undef GEMM
 #undef GEMM_TN
+#undef LN_BWD
+  PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }
