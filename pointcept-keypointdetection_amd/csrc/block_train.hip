@@ -141,8 +141,8 @@ extern "C" int ptv3_block_train_fwd(const ptv3_block_train* b, void* stream) {
                 PTV3_ACT_NONE, nullptr, nullptr, nullptr, dt, scratch, sb, s));
   TRY(ptv3_gemm(b->c1, b->w_lin, b->c2, n, c, c, 1, nullptr, nullptr, b->b_lin, nullptr, nullptr, PTV3_ACT_NONE, nullptr,
                 nullptr, nullptr, dt, scratch, sb, s));
-  TRY(ptv3_layernorm(b->c2, b->g0, b->b0, b->feat, b->f1, nullptr, nullptr, nullptr, n, c, b->eps, dt, s));
-  TRY(ptv3_layernorm(b->f1, b->g1, b->b1, nullptr, b->t3, nullptr, nullptr, nullptr, n, c, b->eps, dt, s));
+  // f1 = feat + LN0(c2) and t3 = LN1(f1) in one pass over the rows
+  TRY(ptv3_layernorm(b->c2, b->g0, b->b0, b->feat, b->f1, b->g1, b->b1, b->t3, n, c, b->eps, dt, s));
   TRY(ptv3_gemm(b->t3, b->w_qkv, b->qkv, n, c, 3 * c, 1, nullptr, nullptr, b->b_qkv, nullptr, nullptr, PTV3_ACT_NONE,
                 nullptr, nullptr, nullptr, dt, scratch, sb, s));
   if (b->cu_seqlens)
