@@ -16,20 +16,15 @@ def timeit(f, it=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t) / it * 1e6
 
 
-masks = [int(a) for a in sys.argv[1:]] or [0]
 shapes = [("qkv", 56504, 256, 768), ("proj", 56504, 256, 256), ("fc1", 56504, 256, 1024), ("fc2", 56504, 1024, 256),
           ("fc1", 27743, 512, 2048), ("fc2", 27743, 2048, 512), ("fc1", 80168, 128, 512), ("proj", 120000, 64, 64)]
-print(f"{'shape':34s}{'64pt us':>9s}" + "".join(f"{'big[%d] us' % m:>12s}" for m in masks) + f"{'TF/s':>8s}{'GB/s':>8s}")
+print(f"{'shape':34s}{'64pt us':>9s}{'128x128 us':>12s}{'TF/s':>8s}{'GB/s':>8s}")
 for name, m, k, n in shapes:
     x = torch.randn(m, k, device=dev).bfloat16(); w = torch.randn(n, k, device=dev).bfloat16(); b = torch.randn(n, device=dev)
-    os.environ["PTV3_GEMM_BIG"] = "0"; os.environ.pop("PTV3_GEMM_DEBUG", None)
+    os.environ["PTV3_GEMM_BIG"] = "0"
     t0 = timeit(lambda: ops.gemm(x, w, bias=b))
     os.environ["PTV3_GEMM_BIG"] = "2"
-    ts = []
-    for mk in masks:
-        os.environ["PTV3_GEMM_DEBUG"] = str(mk)
-        ts.append(timeit(lambda: ops.gemm(x, w, bias=b)))
-    os.environ.pop("PTV3_GEMM_DEBUG", None)
+    ts = [timeit(lambda: ops.gemm(x, w, bias=b))]
     fl, by = 2.0 * m * k * n, 2.0 * (m * k + n * k + m * n)
     print(f"{name:5s} M={m:<7d}K={k:<5d}N={n:<6d}{t0:9.1f}" + "".join(f"{t:12.1f}" for t in ts) +
           f"{fl / ts[0] / 1e6:8.1f}{by / ts[0] / 1e3:8.0f}", flush=True)
@@ -41,13 +36,10 @@ nbr, _ = ops.subm_neighbors(idx, 3)
 n = idx.shape[0]
 for C in (256,):
     x = torch.randn(n, C, device=dev).bfloat16(); w = torch.randn(C, 27 * C, device=dev).bfloat16()
-    os.environ["PTV3_GEMM_BIG"] = "0"; os.environ.pop("PTV3_GEMM_DEBUG", None)
+    os.environ["PTV3_GEMM_BIG"] = "0"
     t0 = timeit(lambda: ops.gemm(x, w, nbr=nbr, kvol=27))
     os.environ["PTV3_GEMM_BIG"] = "2"
-    ts = []
-    for mk in masks:
-        os.environ["PTV3_GEMM_DEBUG"] = str(mk)
-        ts.append(timeit(lambda: ops.gemm(x, w, nbr=nbr, kvol=27)))
+    ts = [timeit(lambda: ops.gemm(x, w, nbr=nbr, kvol=27))]
     act = float((nbr >= 0).float().mean())
     print(f"conv  M={n:<7d}C={C:<5d}active={act:5.2f} {t0:9.1f}" + "".join(f"{t:12.1f}" for t in ts) +
           f"{2.0 * n * 27 * C * C / ts[0] / 1e6:8.1f}", flush=True)

@@ -1,3 +1,6 @@
+"""Level-by-level comparison of the "Swin3D-v1m1" forward with oracle/swin3d.py (stem, every stage, every down / upsampling):
+prints the relative L2 error and the number of rows off by more than 1e-3 per tap - how the reciprocal-multiply division in
+the voxelisation was found.  usage (GPU box): python tools/trace_swin_levels.py"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
