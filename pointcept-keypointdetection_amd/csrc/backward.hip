@@ -12,24 +12,32 @@ namespace ptv3 {
 // ------------------------------------------------------------------------------------------------
 // out[j] = sum_s slab[s][j]   (slab order = fixed summation order)
 // ------------------------------------------------------------------------------------------------
-// thread = (one of 16 columns, one of 16 slab lanes): lane z sums slabs z, z+16, ... in order, the 16 lane
-// sums are then added in lane order (fixed tree: deterministic)
-__global__ void __launch_bounds__(256) slab_sum_kernel(const float* __restrict__ slab, int nslab, int64_t n,
-                                                       float* __restrict__ out, int64_t n0, float* __restrict__ out1) {
-  __shared__ float red[16][17];
-  const int c = threadIdx.x & 15, z0 = threadIdx.x >> 4;
-  const int64_t j = (int64_t)blockIdx.x * 16 + c;
+// block = 64 columns x 16 slab lanes (1024 threads): a wave reads 256 contiguous bytes of one slab row, lane z sums slabs
+// z, z+16, ... in order, the 16 lane sums are then added in lane order (fixed tree: deterministic).  (With 16 columns per
+// block the reads were 64-byte pieces: 59 us for the ~30 MB of slabs of one block backward.)
+constexpr int SS_COLS = 64, SS_LANES = 16;
+__device__ __forceinline__ void slab_sum_body(const float* __restrict__ slab, int nslab, long long n, float* __restrict__ out,
+                                              long long n0, float* __restrict__ out1, long long col_block) {
+  __shared__ float red[SS_LANES][SS_COLS + 1];
+  const int c = threadIdx.x & (SS_COLS - 1), z0 = threadIdx.x / SS_COLS;
+  const long long j = col_block * SS_COLS + c;
   float s = 0.f;
   if (j < n)
-    for (int z = z0; z < nslab; z += 16) s += slab[(int64_t)z * n + j];
+    for (int z = z0; z < nslab; z += SS_LANES) s += slab[(long long)z * n + j];
   red[z0][c] = s;
   __syncthreads();
   if (z0 == 0 && j < n) {
     float t = 0.f;
 #pragma unroll
-    for (int z = 0; z < 16; ++z) t += red[z][c];
+    for (int z = 0; z < SS_LANES; ++z) t += red[z][c];
     if (j < n0) out[j] = t; else out1[j - n0] = t;   // entries n0 .. n-1 of a slab row go to a second buffer
   }
+}
+
+__global__ void __launch_bounds__(SS_COLS * SS_LANES) slab_sum_kernel(const float* __restrict__ slab, int nslab, int64_t n,
+                                                                      float* __restrict__ out, int64_t n0,
+                                                                      float* __restrict__ out1) {
+  slab_sum_body(slab, nslab, n, out, n0, out1, blockIdx.x);
 }
 
 // Deferred reductions: a caller that issues several slab-producing kernels back to back (the native block backward:
@@ -42,31 +50,19 @@ struct SlabSegs { SlabSeg v[SLAB_SEGS]; };
 static thread_local SlabSegs* g_defer = nullptr;
 static thread_local int g_defer_count = 0, g_defer_blocks = 0;
 
-__global__ void __launch_bounds__(256) slab_sum_multi_kernel(SlabSegs segs, int nseg) {
-  __shared__ float red[16][17];
+__global__ void __launch_bounds__(SS_COLS * SS_LANES) slab_sum_multi_kernel(SlabSegs segs, int nseg) {
   int k = 0;
 #pragma unroll 1
   for (int t = 1; t < nseg; ++t)
     if (segs.v[t].first_block <= (int)blockIdx.x) k = t;
   const SlabSeg g = segs.v[k];
-  const int c = threadIdx.x & 15, z0 = threadIdx.x >> 4;
-  const long long j = (long long)((int)blockIdx.x - g.first_block) * 16 + c;
-  float s = 0.f;
-  if (j < g.n)
-    for (int z = z0; z < g.nslab; z += 16) s += g.slab[(long long)z * g.n + j];
-  red[z0][c] = s;
-  __syncthreads();
-  if (z0 == 0 && j < g.n) {
-    float t = 0.f;
-#pragma unroll
-    for (int z = 0; z < 16; ++z) t += red[z][c];
-    if (j < g.n0) g.out[j] = t; else g.out1[j - g.n0] = t;
-  }
+  slab_sum_body(g.slab, g.nslab, g.n, g.out, g.n0, g.out1, (int)blockIdx.x - g.first_block);
 }
 
 int slab_defer_flush(hipStream_t s) {
   if (g_defer && g_defer_count > 0)
-    hipLaunchKernelGGL(slab_sum_multi_kernel, dim3((unsigned)g_defer_blocks), dim3(256), 0, s, *g_defer, g_defer_count);
+    hipLaunchKernelGGL(slab_sum_multi_kernel, dim3((unsigned)g_defer_blocks), dim3(SS_COLS * SS_LANES), 0, s, *g_defer,
+                       g_defer_count);
   g_defer_count = g_defer_blocks = 0;
   return PTV3_OK;
 }
@@ -83,11 +79,11 @@ static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStr
     SlabSeg& g = g_defer->v[g_defer_count++];
     g.slab = slab; g.out = out; g.out1 = out1; g.n = n; g.n0 = n0 < 0 ? n : n0; g.nslab = nslab;
     g.first_block = g_defer_blocks;
-    g_defer_blocks += (int)cdiv(n, 16);
+    g_defer_blocks += (int)cdiv(n, SS_COLS);
     return;
   }
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, 16)), dim3(256), 0, s, slab, nslab, n, out,
-                     n0 < 0 ? n : n0, out1);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, SS_COLS)), dim3(SS_COLS * SS_LANES), 0, s, slab, nslab, n,
+                     out, n0 < 0 ? n : n0, out1);
 }
 
 // ------------------------------------------------------------------------------------------------
