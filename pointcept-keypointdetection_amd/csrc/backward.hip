@@ -102,6 +102,7 @@ struct TnArgs {
   float* dbias;   // NULL, or where chunk z writes its column sums of dy: dbias + z * slab_stride (cout floats)
   int64_t m, rows_per_chunk, slab_stride;
   int cout, cin, kvol, tiles_c;
+  int packed;   // narrow convolutions (cin < 64): the 64 columns of a tile run over (tap, channel), several taps per tile
 };
 
 // Rows per staged block RB (k-steps of 16 rows, RB/64 per wave) and LDS row stride LS (elements).  One block = one
@@ -122,9 +123,9 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int to = blockIdx.x / a.tiles_c, tc = blockIdx.x % a.tiles_c;
-  const int tap = blockIdx.y;
   const int o0 = 64 * to, c0 = 64 * tc;
-  const int nto = (min(64, a.cout - o0) + 15) / 16, ntc = (min(64, a.cin - c0) + 15) / 16;
+  const int ncols = a.packed ? a.kvol * a.cin : a.cin;   // column space of this launch's tiles
+  const int nto = (min(64, a.cout - o0) + 15) / 16, ntc = (min(64, ncols - c0) + 15) / 16;
   const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_chunk;
   const int64_t r1 = r0 + a.rows_per_chunk < a.m ? r0 + a.rows_per_chunk : a.m;
   f32x4 acc[4][4];
@@ -136,13 +137,16 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   // staging: each thread owns NJ 4-row x 4-channel patches of both operands (rows 64j + 4rg .. +3, channels 4cg .. +3),
   // transposes them in registers and stores 4 x (4 consecutive rows of one channel) per patch
   const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
-  const bool oka = o0 + 4 * cg < a.cout, okb = c0 + 4 * cg < a.cin;
+  const int mycol = c0 + 4 * cg;                                   // this thread's 4 columns of the gathered operand
+  const int tap = a.packed ? mycol / a.cin : (int)blockIdx.y;      // packed: a tile spans 64 / cin taps
+  const int mych = a.packed ? mycol % a.cin : mycol;
+  const bool oka = o0 + 4 * cg < a.cout, okb = mycol < ncols;
   V4 ra[NJ][4], rb[NJ][4];
   // Every load is issued unconditionally from an in-range address and the value dropped afterwards: a load inside a
   // branch makes the compiler wait for ALL outstanding loads (vmcnt(0)) at the branch, which serialised the
   // index -> row chains of a thread's rows; this way the indices of all rows are in flight together, then all rows.
   const int64_t rlast = r1 - 1;                    // r1 > r0: a chunk is never empty
-  const int ca = oka ? o0 + 4 * cg : 0, cb = okb ? c0 + 4 * cg : 0;
+  const int ca = oka ? o0 + 4 * cg : 0, cb = okb ? mych : 0;
   auto fetch = [&](int64_t rblk) {
     int src[NJ][4];
 #pragma unroll
@@ -151,7 +155,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
       for (int u = 0; u < 4; ++u) {
         const int64_t r = rblk + 64 * j + 4 * rg + u;
         const int64_t rc = r < r1 ? r : rlast;
-        src[j][u] = a.nbr ? a.nbr[rc * a.kvol + tap] : (int)rc;
+        src[j][u] = a.nbr ? a.nbr[rc * a.kvol + (okb ? tap : 0)] : (int)rc;
         ra[j][u] = *reinterpret_cast<const V4*>(dy + rc * a.cout + ca);
       }
 #pragma unroll
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   };
   // bias gradient (column sums of dy) as a by-product of the staging: this thread sees channels o0 + 4cg .. +3 of
   // every row block; only the workgroups of the first input-channel tile / first tap keep them
-  const bool want_b = a.dbias != nullptr && tc == 0 && tap == 0;
+  const bool want_b = a.dbias != nullptr && tc == 0 && (a.packed || blockIdx.y == 0);
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
   fetch(r0);
   for (int64_t rblk = r0; rblk < r1; rblk += RB) {
@@ -263,9 +267,11 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = o0 + 16 * p + 4 * g + r, c = c0 + 16 * q + i;
-          if (o < a.cout && c < a.cin) out[o * ld + (int64_t)tap * a.cin + c] = acc[p][q][r];
+          if (o < a.cout && c < ncols) out[o * ld + (a.packed ? 0 : (int64_t)blockIdx.y * a.cin) + c] = acc[p][q][r];
         }
 }
+
+static bool tn_packed(int cin, int kvol) { return kvol > 1 && cin < 64 && 64 % cin == 0; }
 
 static int64_t tn_chunks(int64_t m, int cout, int cin, int kvol, int64_t* rows_per_chunk) {
   // Row chunks (= fp32 slabs, summed in order afterwards).  A workgroup's time is rounds of load -> LDS -> MFMA whose
@@ -273,7 +279,8 @@ static int64_t tn_chunks(int64_t m, int cout, int cin, int kvol, int64_t* rows_p
   // per CU) of a few rounds each rather than a few long ones: with the earlier cap of 64 chunks the weight gradient of a
   // 100k x 96 x 32 linear ran on 126 workgroups (50 us for 26 MB of operands).  The slabs bound it from the other side:
   // every chunk writes and the reduction reads cout x kvol x cin floats, held to ~32 MB per launch.
-  const int64_t tiles = cdiv(cout, 64) * cdiv(cin, 64) * kvol;
+  const int64_t tiles = tn_packed(cin, kvol) ? cdiv(cout, 64) * cdiv((int64_t)kvol * cin, 64)
+                                             : cdiv(cout, 64) * cdiv(cin, 64) * kvol;
   int64_t want = cdiv(2048, tiles);
   const int64_t slab_cap = (32ll << 20) / ((int64_t)cout * cin * kvol * 4);
   if (want > slab_cap) want = slab_cap;
@@ -646,8 +653,9 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
   a.out = ns > 1 ? (float*)workspace : dw;
   a.dbias = !dbias ? nullptr : (ns > 1 ? (float*)workspace + nw : dbias);
   a.m = m; a.rows_per_chunk = rpc; a.slab_stride = ns > 1 ? nw + (dbias ? cout : 0) : 0;
-  a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)cdiv(cin, 64);
-  dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)kvol, (unsigned)ns);
+  a.packed = tn_packed(cin, kvol) ? 1 : 0;
+  a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)(a.packed ? cdiv((int64_t)kvol * cin, 64) : cdiv(cin, 64));
+  dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)(a.packed ? 1 : kvol), (unsigned)ns);
   // LDS: two [64][LS] operand blocks; the 64 x 64 fp32 cross-wave reduction reuses them after the last block
   static int rbsel = -1;
   if (rbsel < 0) { const char* e = getenv("PTV3_TN_RB"); rbsel = e ? atoi(e) : 64; }
