@@ -41,6 +41,9 @@ def window_attn_args(coords, stride, window_size, local_xyz, signals, shift=0):
     _, w_w_xyz, w_sizes, n2n, _, _ = ops.swin_window_mapping(coords, stride, window_size, shift)
     n_coords = torch.cat([w_w_xyz.float() + local_xyz[n2n], signals[n2n]], dim=1)
     x_off, y_off, m2w, w_sizes, w2n, w2m = sparse_self_attention(w_sizes)
+    # the largest window, fetched once per partition (one sync): the attention kernel sizes its LDS by it instead of by
+    # window_size^3 occupied cells, which surfaces never reach
+    w_sizes._ptv3_max_tokens = int(w_sizes.max()) if w_sizes.numel() else 1
     return x_off, y_off, m2w, w_sizes, w2n, n2n, w2m, n_coords
 
 
@@ -92,7 +95,7 @@ class WindowAttention(nn.Module):
         w_start = torch.cat([w2n, w2n.new_tensor([num_v])]).int()
         out = ops.swin_attention(query.contiguous(), qkv[1], qkv[2], self._tables("query"), self._tables("key"),
                                  self._tables("value"), self.table_offsets, n2n, w_start, n_crse,
-                                 self.window_size ** 3)
+                                 getattr(w_sizes, "_ptv3_max_tokens", self.window_size ** 3))
         return self.proj(out.view(num_v, self.dim))
 
 
