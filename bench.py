@@ -335,6 +335,42 @@ def semseg_lidar_workload(device, args, world):
             "forwards_in_flight": 1, "stage_points": pts}
 
 
+def swin3d_workload(device, points=300000):
+    """BASELINE configs[4] beside the headline: "Swin3D-v1m1" (Swin3D-S, the S3DIS config: 9 input channels, colour + normal
+    signals, 5^3 / 7^3-voxel windows with cRSE tables) forward on one room-like scene.  fp32, random weights, inference
+    only; PARITY UNPINNED (MinkowskiEngine / microsoft/Swin3D are not in the reference tree - DESIGN.md section 10)."""
+    import numpy as np
+    from ptv3_hip import configs
+    from pointcept.models import build_model as build
+    rng = np.random.default_rng(0)
+    extent = int((points / 1.2) ** 0.5)
+    xy = rng.uniform(0, extent, size=(3 * points, 2))
+    z = extent / 2 + 6.0 * np.sin(xy[:, 0] / 19.0) * np.cos(xy[:, 1] / 17.0) + rng.normal(0, 0.4, 3 * points)
+    g = np.unique(np.floor(np.concatenate([xy, z[:, None]], 1)).astype(np.int64), axis=0)
+    g = g[rng.permutation(len(g))[:points]]
+    n = len(g)
+    batch = {"coord": torch.from_numpy(((g + rng.random(g.shape)) * 0.02).astype(np.float32)).to(device),
+             "grid_coord": torch.from_numpy(g).to(device),
+             "feat": torch.from_numpy(rng.normal(size=(n, 9)).astype(np.float32)).to(device),
+             "coord_feat": torch.from_numpy(rng.uniform(-1, 1, (n, 6)).astype(np.float32)).to(device),
+             "offset": torch.tensor([n], device=device)}
+    torch.manual_seed(0)
+    model = build(configs.SWIN3D_S3DIS_CFG).to(device).eval()
+    with torch.no_grad():
+        for _ in range(2):
+            y = model(dict(batch))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            y = model(dict(batch))
+        torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    return {"workload": f"Swin3D-v1m1 (Swin3D-S, S3DIS config, 28.2M params) eval forward, 1 x {n}-point room-like scene, "
+                        "fp32, random weights; parity unpinned", "value": round(n / ms / 1e3, 4), "unit": "Mpoints/s",
+            "ms_per_step": round(ms, 2), "finite": bool(torch.isfinite(y).all().item())}
+
+
 def train_bench(args, model, device, world, rank, local_rank):
     """Train step of the fork config: forward + backward (HIP Functions) + fused AdamW; gradients are averaged by
     DistributedDataParallel over RCCL (one bucketed all-reduce of the 46.2M fp32 gradients, overlapped with
@@ -524,6 +560,8 @@ def run(args):
         del model, batch
         torch.cuda.empty_cache()
         extra = {"semseg_lidar_120k": semseg_lidar_workload(device, args, world)}
+        torch.cuda.empty_cache()
+        extra["swin3d_s3dis_300k"] = swin3d_workload(device)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
