@@ -534,6 +534,16 @@ int ptv3_swin_attn_fwd(const void* q, const void* k, const void* v, const float*
                        const int32_t* w_start, int num_windows, const float* n_crse, void* out, int64_t n, int heads,
                        int head_dim, int max_tokens, int dtype, void* stream);
 
+/* backward of ptv3_swin_attn_fwd (the reference: SelfAttnAIOFunction.backward of the absent microsoft/Swin3D; checked
+ * against torch autograd over the restated forward: parity unpinned).  dout (n, heads, head_dim) in dtype; writes dq, dk, dv
+ * (same shape / dtype) and the fp32 gradients of the three concatenated tables (sum(table_offsets) elements each; zeroed
+ * here, then accumulated with atomics: their last bits depend on the order of additions). */
+int ptv3_swin_attn_bwd(const void* q, const void* k, const void* v, const void* dout, const float* q_table,
+                       const float* k_table, const float* v_table, const int32_t* table_offsets_host, int num_axes,
+                       const int64_t* n2n, const int32_t* w_start, int num_windows, const float* n_crse, void* dq,
+                       void* dk, void* dv, float* dq_table, float* dk_table, float* dv_table, int64_t n, int heads,
+                       int head_dim, int max_tokens, int dtype, void* stream);
+
 /* ---- pointops (libs/pointops) ------------------------------------------------------------------
  * Same argument meaning as the reference's extern "C" launchers
  * (libs/pointops/src/knn_query/knn_query_cuda_kernel.h:9-17, grouping/grouping_cuda_kernel.h,

@@ -283,6 +283,32 @@ class WindowAttentionRpeFn(Function):
         return dqkv, dtable.to(pdtype), None, None, None, None, None, None, None
 
 
+class SwinAttentionFn(Function):
+    """Swin3D cRSE window attention (ops.swin_attention; swin3d_layers.py:556-569) with its HIP backward: gradients of
+    q, k, v and of the three concatenated tables."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, q_table, k_table, v_table, table_offsets, n2n, w_start, n_crse, max_tokens):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        tabs = [t.detach().float().contiguous() for t in (q_table, k_table, v_table)]
+        out = ops.swin_attention(q, k, v, *tabs, table_offsets, n2n, w_start, n_crse, max_tokens)
+        ctx.save_for_backward(q, k, v, *tabs, n2n, w_start, n_crse)
+        ctx.cfg = (tuple(int(t) for t in table_offsets), int(max_tokens), q_table.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, qt, kt, vt, n2n, w_start, n_crse = ctx.saved_tensors
+        offs, max_tokens, tdt = ctx.cfg
+        dq, dk, dv, dqt, dkt, dvt = ops.swin_attention_bwd(q, k, v, dout.contiguous(), qt, kt, vt, offs, n2n, w_start,
+                                                           n_crse, max_tokens)
+        return dq, dk, dv, dqt.to(tdt), dkt.to(tdt), dvt.to(tdt), None, None, None, None, None
+
+
+def swin_attention(q, k, v, q_table, k_table, v_table, table_offsets, n2n, w_start, n_crse, max_tokens):
+    return SwinAttentionFn.apply(q, k, v, q_table, k_table, v_table, table_offsets, n2n, w_start, n_crse, max_tokens)
+
+
 class SegmentMaxFn(Function):
     """torch_scatter.segment_csr(feat[indices], idx_ptr, reduce="max") (:416-421) over serialized-order runs."""
 

@@ -115,6 +115,8 @@ SIGNATURES = {
     "ptv3_profile_collect_kernels": (c_int, [P, P, P, P]),
     "ptv3_swin_window_keys": (c_int, [P, c_int64, c_int, c_int, c_int, P, P, P]),
     "ptv3_swin_attn_fwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int, P, P, c_int64, c_int, c_int, c_int, c_int, P]),
+    "ptv3_swin_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, c_int,
+                                   c_int, c_int, P]),
     "ptv3_knn_query": (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, P]),
     "ptv3_knn_query_cells": (c_int, [c_int, c_int, P, P, P, P, c_int64, P, P, P, c_float, P, P, P]),
     "ptv3_grouping_forward": (c_int, [c_int, c_int, c_int, P, P, P, P]),

@@ -760,6 +760,33 @@ def swin_attention(q, k, v, q_table, k_table, v_table, table_offsets, n2n, w_sta
     return out
 
 
+def swin_attention_bwd(q, k, v, dout, q_table, k_table, v_table, table_offsets, n2n, w_start, n_crse, max_tokens):
+    """-> dq, dk, dv (n, H, D) in the dtype of q and dq_table, dk_table, dv_table (fp32, flat like the tables)."""
+    _chk(q, "q", _F, 3)
+    for name, t in (("k", k), ("v", v), ("dout", dout)):
+        _chk(t, name, q.dtype, 3)
+        if t.shape != q.shape:
+            raise ValueError(f"swin_attention_bwd: {name} {tuple(t.shape)} vs q {tuple(q.shape)}")
+    for name, t in (("q_table", q_table), ("k_table", k_table), ("v_table", v_table)):
+        _chk(t, name, torch.float32, 1)
+    _chk(n2n, "n2n", torch.int64, 1)
+    _chk(w_start, "w_start", torch.int32, 1)
+    _chk(n_crse, "n_crse", torch.float32, 2)
+    n, heads, hd = q.shape
+    axes = len(table_offsets)
+    total = int(sum(int(t) for t in table_offsets))
+    if n_crse.shape != (n, axes) or n2n.shape[0] != n or min(q_table.numel(), k_table.numel(), v_table.numel()) < total:
+        raise ValueError("swin_attention_bwd: shapes of n_crse / n2n / tables do not fit")
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    dtab = torch.empty((3, total), dtype=torch.float32, device=q.device)
+    offs = (ctypes.c_int32 * axes)(*[int(t) for t in table_offsets])
+    lib.check(lib.ptv3_swin_attn_bwd(_p(q), _p(k), _p(v), _p(dout), _p(q_table), _p(k_table), _p(v_table), offs, axes,
+                                     _p(n2n), _p(w_start), w_start.shape[0] - 1, _p(n_crse), _p(dq), _p(dk), _p(dv),
+                                     _p(dtab[0]), _p(dtab[1]), _p(dtab[2]), n, heads, hd, int(max_tokens), _dt(q),
+                                     _stream()), "ptv3_swin_attn_bwd")
+    return dq, dk, dv, dtab[0], dtab[1], dtab[2]
+
+
 # ---------------------------------------------------------------------------------------------
 # keypoint aggregation (after the model)
 # ---------------------------------------------------------------------------------------------

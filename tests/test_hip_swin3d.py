@@ -314,3 +314,58 @@ def test_offset_keypoint_swin3d_wrapper(dev):
     got = out["pred"].cpu().numpy()
     assert _rel(got, want) <= 1e-4, _rel(got, want)
     assert "coord_feat" in data and torch.isfinite(out["loss"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# backward of the cRSE attention
+# ---------------------------------------------------------------------------------------------------------------
+def _crse_attention_torch(q, k, v, qt, kt, vt, offs, w_sizes, w2n, n2n, cr):
+    """Differentiable torch (float64, CPU) restatement of oracle.swin3d.crse_attention: the checker of the HIP backward
+    (torch autograd over the forward this package computes; the reference's own backward lives in the absent
+    microsoft/Swin3D: parity unpinned)."""
+    n, h, d = q.shape
+    starts = np.concatenate([[0], np.cumsum(offs)])
+    outs, rows_all = [], []
+    for w in range(len(w_sizes)):
+        m, s0 = int(w_sizes[w]), int(w2n[w])
+        rows = torch.as_tensor(np.asarray(n2n[s0:s0 + m], np.int64))
+        c = cr[s0:s0 + m]
+        Q, K, V = q[rows], k[rows], v[rows]
+        logit = torch.einsum("ihd,jhd->hij", Q, K)
+        vsum = 0
+        for a in range(len(offs)):
+            nrow = int(offs[a]) // (h * d)
+            sl = slice(int(starts[a]), int(starts[a + 1]))
+            idx = np.floor((c[:, None, a] - c[None, :, a]) + np.float32(nrow // 2)).astype(np.int64).clip(0, nrow - 1)
+            idx = torch.from_numpy(idx)
+            tq, tk, tv = (t[sl].view(nrow, h, d)[idx] for t in (qt, kt, vt))
+            logit = logit + torch.einsum("ihd,ijhd->hij", Q, tk) + torch.einsum("jhd,ijhd->hij", K, tq)
+            vsum = vsum + tv
+        p = torch.softmax(logit, -1)
+        outs.append(torch.einsum("hij,jhd->ihd", p, V) + torch.einsum("hij,ijhd->ihd", p, vsum))
+        rows_all.append(rows)
+    out = torch.zeros_like(q)
+    return out.index_put((torch.cat(rows_all),), torch.cat(outs))
+
+
+@pytest.mark.parametrize("heads,hd,ws,quant,crse", [(3, 8, 5, 4, "XYZ_RGB_NORM"), (2, 16, 7, 4, "XYZ_RGB"),
+                                                     (2, 16, 5, 50, "XYZ_RGB"), (2, 32, 5, 4, "XYZ")])
+def test_crse_attention_backward_vs_torch_autograd(dev, heads, hd, ws, quant, crse):
+    """ptv3_swin_attn_bwd: dq, dk, dv and the three table gradients against torch autograd (float64) over the restated
+    forward, relative L2 <= 1e-4 each.  The fork's training config (quant 50, XYZ_RGB, head_dim 16) is one of the cases."""
+    from ptv3_hip import autograd as A
+    coords = _surface(1500, 40, heads + hd + ws)
+    q, k, v, tabs, offs, w_sizes, w2n, n2n, cr = _case(coords, heads, hd, ws, quant, crse, seed=3, table_std=0.3)
+    rng = np.random.default_rng(1)
+    dout = rng.normal(size=q.shape).astype(np.float32)
+    ref_in = [torch.from_numpy(a).double().requires_grad_(True) for a in (q, k, v, *tabs)]
+    ref = _crse_attention_torch(*ref_in, offs, w_sizes, w2n, n2n, cr)
+    ref.backward(torch.from_numpy(dout).double())
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dev_in = [t(a).requires_grad_(True) for a in (q, k, v, *tabs)]
+    w_start = t(np.concatenate([w2n, [len(q)]]).astype(np.int32))
+    out = A.swin_attention(*dev_in, offs, t(n2n.astype(np.int64)), w_start, t(cr), int(w_sizes.max()))
+    assert _rel(out.detach().cpu().numpy(), ref.detach().numpy()) <= 1e-4
+    out.backward(t(dout))
+    for name, a, b in zip(("dq", "dk", "dv", "dq_table", "dk_table", "dv_table"), dev_in, ref_in):
+        assert _rel(a.grad.cpu().numpy(), b.grad.numpy()) <= 1e-4, (name, _rel(a.grad.cpu().numpy(), b.grad.numpy()))
