@@ -4,7 +4,7 @@ Contract of the reference class (pointcept/models/offset_keypoint_swin3d.py:5-13
 `backbone_conf, num_keypoints, hidden_dim`; state_dict = `backbone.*` + `head.{0,1,3}.*`; `coord_feat` is built from
 `feat` (or `coord` + `feat` when the stem expects three more channels, :38-56) when the batch does not carry one; eval
 returns `pred` (N, K, 4) with the score column through a sigmoid (:125-128) and, when the batch carries `target`, the
-loss of :73-88 (BCE on the score + 2 x masked L1 on the offsets).  Training raises in the backbone (forward-only path).
+loss of :73-88 (BCE on the score + 2 x masked L1 on the offsets); training returns the loss alone (:125).
 """
 import torch
 import torch.nn as nn
@@ -32,9 +32,8 @@ class OffsetKeypointSwin3D(nn.Module):
             expected = self.backbone.stem_layer.conv_layers[0].in_channels
             data_dict["coord_feat"] = torch.cat([coord, feat], dim=1) if expected == feat.shape[1] + 3 else feat
         feat = self.backbone(data_dict)
-        x = self.head[0](feat.contiguous())
-        scale, shift = self.head[1].folded()
-        pred = self.head[3](ops.affine_act(x, scale, shift, ops.ACT_RELU)).float().view(-1, self.num_keypoints, 4)
+        x = self.head[1](self.head[0](feat.contiguous()), act=ops.ACT_RELU)
+        pred = self.head[3](x).float().view(-1, self.num_keypoints, 4)
         result = {}
         if "target" in data_dict:
             target = data_dict["target"]
@@ -43,7 +42,8 @@ class OffsetKeypointSwin3D(nn.Module):
             valid = (mask_gt > 0.5).float().unsqueeze(-1)
             reg = (self.reg_criterion(pred[..., :3], target[..., :3]) * valid).sum() / (valid.sum() * 3 + 1e-6)
             result["loss"] = cls_loss + reg * 2.0
-        final = pred.clone()
-        final[..., 3] = torch.sigmoid(pred[..., 3])
-        result["pred"] = final
+        if not self.training:
+            final = pred.clone()
+            final[..., 3] = torch.sigmoid(pred[..., 3])
+            result["pred"] = final
         return result

@@ -9,15 +9,15 @@ tensors instead of MinkowskiEngine sparse tensors, and `WindowStage` is the bloc
 PARITY UNPINNED: the reference runs this arithmetic in MinkowskiEngine and microsoft/Swin3D, neither of which is in
 its tree; oracle/swin3d.py restates it and is the only checker (see its header for what is an assumption).
 
-NOT built (so "Swin3D-v1m1" / "OffsetKeypointSwin3D" are not registered): the MinkowskiEngine voxel-average
-quantisation and stem convolution (swin3d_v1m1_base.py:162-194), GridKNNDownsample / Upsample with Swin3D's own KNN
-(swin3d_layers.py:274-378), and the backward of the attention (inference only: training raises).
+Training: every layer is a taped Function with a HIP backward (ptv3_swin_attn_bwd for the attention, the PTv3 path's
+Functions for Linear / LayerNorm / GELU); attention dropout (`attn_drop` > 0) is not implemented and raises.
 """
 import numpy as np
 import torch
 import torch.nn as nn
 
 from ptv3_hip import ops
+from ptv3_hip import autograd as A
 from pointcept.models.utils.hip_layers import Linear, LayerNorm, GELU, DropPath
 
 
@@ -74,17 +74,20 @@ class WindowAttention(nn.Module):
             self.table_offsets += [int(np.prod(shape[1:]))] * 3
             self._groups.append((name, quant))
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
+        if attn_drop > 0.0:
+            raise NotImplementedError("Swin3D WindowAttention: attn_drop > 0 (dropout inside the attention) is not built")
         self.attn_drop = nn.Dropout(attn_drop, inplace=True)
         self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop, inplace=True)
 
     def _tables(self, kind):
-        return torch.cat([getattr(self, f"{kind}_{name}_table").detach().float().reshape(-1)
-                          for name, _ in self._groups])
+        """the concatenated table of :503-528 (a differentiable view of the parameters in training)"""
+        parts = [getattr(self, f"{kind}_{name}_table").reshape(-1) for name, _ in self._groups]
+        if not self.training:
+            parts = [p.detach().float() for p in parts]
+        return torch.cat(parts)
 
     def forward(self, feats, attn_args):
-        if self.training:
-            raise NotImplementedError("Swin3D WindowAttention: the HIP path has the forward only (inference)")
         (_, _, _, w_sizes, w2n, n2n, _, n_coords) = attn_args
         num_v = feats.shape[0]
         hd = self.dim // self.num_heads
@@ -93,10 +96,11 @@ class WindowAttention(nn.Module):
         n_crse = torch.cat([n_coords[:, 3 * i:3 * i + 3] * float(q) for i, (_, q) in enumerate(self._groups)],
                            dim=1).float().contiguous()                                # :505-530
         w_start = torch.cat([w2n, w2n.new_tensor([num_v])]).int()
-        out = ops.swin_attention(query.contiguous(), qkv[1], qkv[2], self._tables("query"), self._tables("key"),
-                                 self._tables("value"), self.table_offsets, n2n, w_start, n_crse,
-                                 getattr(w_sizes, "_ptv3_max_tokens", self.window_size ** 3))
-        return self.proj(out.view(num_v, self.dim))
+        max_tokens = getattr(w_sizes, "_ptv3_max_tokens", self.window_size ** 3)
+        attend = A.swin_attention if self.training else ops.swin_attention      # training: taped, with its HIP backward
+        out = attend(query.contiguous(), qkv[1], qkv[2], self._tables("query"), self._tables("key"),
+                     self._tables("value"), self.table_offsets, n2n, w_start, n_crse, max_tokens)
+        return self.proj_drop(self.proj(out.reshape(num_v, self.dim)))
 
 
 class Mlp(nn.Module):

@@ -1,4 +1,4 @@
-"""Swin3D U-Net on MI355X: registry name "Swin3D-v1m1" (SURVEY.md section 8, rows A19 / f4).  INFERENCE ONLY.
+"""Swin3D U-Net on MI355X: registry name "Swin3D-v1m1" (SURVEY.md section 8, rows A19 / f4).
 
 Counterpart of the reference's pointcept/models/swin3d/swin3d_v1m1_base.py (`Swin3DUNet`, constructor keywords of
 :30-49, module tree and parameter names of :71-146) without MinkowskiEngine: a sparse tensor is a `_Level` (int32
@@ -23,13 +23,15 @@ the stem kernel's 27 taps are read x-fastest (`kernel[t]`, t = (dx+1) + 3 (dy+1)
 Euclidean (as libs/pointops, from which Swin3D's KNN descends); GridCoordsDown keeps the LOWEST-numbered member among
 those within 1e-4 (relative) of the smallest distance to the cell mean (the reference keeps whichever equal-distance
 member's write lands last - in a two-voxel cell both members are equidistant by construction).
-Training raises: the attention has no backward here.
+Training: the same forward with every feature layer taped (Functions of ptv3_hip/autograd.py, the cRSE attention's own
+backward kernel); geometry (voxel ids, window maps, neighbour indices, the signal carriers) carries no gradient.
 """
 import torch
 import torch.nn as nn
 
 import pointops
 from ptv3_hip import ops
+from ptv3_hip import autograd as A
 from pointcept.models.builder import MODELS
 from pointcept.models.utils.hip_layers import Linear, LayerNorm, BatchNorm1d
 from .swin3d_layers import WindowStage
@@ -119,6 +121,11 @@ class _ConvBNRelu(nn.Module):
         w = torch.nn.functional.pad(w, (0, 0, 0, cin_pad - conv.in_channels))
         w = w.permute(2, 0, 1).reshape(conv.out_channels, -1).to(x.dtype).contiguous()
         nbr, _ = ops.subm_neighbors(level.coords, k)
+        if self.training:
+            # taped: the kernel re-indexed to this package's tap order as a differentiable view, batch-statistic BN
+            w5 = conv.kernel[t_me].permute(2, 0, 1).reshape(conv.out_channels, k, k, k, conv.in_channels)
+            level.feat = bn(A.subm_conv(level.feat, w5, None, nbr), act=ops.ACT_RELU)
+            return level
         scale, shift = bn.folded()
         level.feat = ops.gemm(x, w, nbr=nbr, kvol=k ** 3, bn_scale=scale, bn_shift=shift, act=ops.ACT_RELU)
         return level
@@ -154,9 +161,15 @@ class GridKNNDownsample(nn.Module):
         y = self.linear(self.norm(level.feat))
         idx, _ = pointops.knn_query(self.k, level.xyz, level.offset, cfeat[:, 1:4].contiguous(), offset,
                                      cell=float(level.stride))
-        idx = torch.where(idx < 0, idx[:, :1], idx).long().reshape(-1).contiguous()
-        starts = torch.arange(0, (m + 1) * self.k, self.k, device=idx.device, dtype=torch.int32)
-        feat = ops.pool_max(y, idx, starts, m)
+        idx = torch.where(idx < 0, idx[:, :1], idx).long()
+        if self.training:
+            # a source voxel is a neighbour of SEVERAL coarse voxels: its gradient is a sum over them, which the
+            # segment-max backward of the pooling path (every row in exactly one segment) does not form - gather and
+            # max through torch's tape here
+            feat = y[idx].max(dim=1).values
+        else:
+            starts = torch.arange(0, (m + 1) * self.k, self.k, device=idx.device, dtype=torch.int32)
+            feat = ops.pool_max(y, idx.reshape(-1).contiguous(), starts, m)
         return _Level(coords.int().contiguous(), new_stride, feat, cfeat, offset)
 
 
@@ -264,8 +277,6 @@ class Swin3DUNet(nn.Module):
         return level, cluster
 
     def forward(self, data_dict):
-        if self.training:
-            raise NotImplementedError("Swin3D-v1m1: the HIP path has the forward only (inference)")
         level, point2voxel = self.voxelize(data_dict)
         level = self.stem_layer(level)
         skips = []
@@ -275,7 +286,5 @@ class Swin3DUNet(nn.Module):
         level = skips.pop()
         for up in self.upsamples:
             level = up(level, skips.pop())
-        x = self.classifier[0](level.feat)
-        scale, shift = self.classifier[1].folded()
-        x = ops.affine_act(x, scale, shift, ops.ACT_RELU)
+        x = self.classifier[1](self.classifier[0](level.feat), act=ops.ACT_RELU)   # BN: batch statistics in training
         return self.classifier[3](x)[point2voxel]

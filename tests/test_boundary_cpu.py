@@ -196,6 +196,6 @@ def test_swin3d_refuses_what_it_does_not_build():
         build_model(dict(configs.TINY_SWIN3D_CFG, knn_down=False))
     with pytest.raises(NotImplementedError, match="stem_transformer=False"):
         build_model(dict(configs.TINY_SWIN3D_CFG, stem_transformer=False))
-    model = build_model(configs.TINY_SWIN3D_CFG).train()
-    with pytest.raises(NotImplementedError, match="forward only"):
-        model({})
+    with pytest.raises(NotImplementedError, match="attn_drop"):
+        from pointcept.models.swin3d import WindowAttention
+        WindowAttention(32, 5, 4, 2, attn_drop=0.1)
