@@ -337,8 +337,8 @@ def semseg_lidar_workload(device, args, world):
 
 def swin3d_workload(device, points=300000):
     """BASELINE configs[4] beside the headline: "Swin3D-v1m1" (Swin3D-S, the S3DIS config: 9 input channels, colour + normal
-    signals, 5^3 / 7^3-voxel windows with cRSE tables) forward on one room-like scene.  fp32, random weights, inference
-    only; PARITY UNPINNED (MinkowskiEngine / microsoft/Swin3D are not in the reference tree - DESIGN.md section 10)."""
+    signals, 5^3 / 7^3-voxel windows with cRSE tables) forward on one room-like scene.  fp32, random weights;
+    PARITY UNPINNED (MinkowskiEngine / microsoft/Swin3D are not in the reference tree - DESIGN.md section 10)."""
     import numpy as np
     from ptv3_hip import configs
     from pointcept.models import build_model as build

@@ -521,7 +521,7 @@ int ptv3_profile_collect_kernels(double* ms, double* flops, double* bytes, int64
 int ptv3_swin_window_keys(const int32_t* coords, int64_t n, int stride, int window_size, int shift, int64_t* key,
                           int32_t* bad, void* stream);
 /* replaces SelfAttnAIOFunction.apply(..., PosEmb.SEPARATE, TableDims.D0, IndexMode.INDIRECT, ...) at
- * swin3d_layers.py:556-569, forward only.  q, k, v, out: (n, heads, head_dim) in ORIGINAL voxel order, q already
+ * swin3d_layers.py:556-569 (forward; ptv3_swin_attn_bwd below is its backward).  q, k, v, out: (n, heads, head_dim) in ORIGINAL voxel order, q already
  * scaled (:499); {q,k,v}_table: the concatenated fp32 tables of :503-528, table_offsets_host[c] elements per signal
  * axis c (the reference's `table_offsets`, :441/:452/:464), num_axes = 3, 6 or 9; n2n (n) int64: sorted position ->
  * original row (n2n_indices); w_start (num_windows + 1) int32: token range of each window in sorted order

@@ -1,4 +1,4 @@
-"""Keypoint-offset head on the Swin3D backbone: registry name "OffsetKeypointSwin3D" (inference).
+"""Keypoint-offset head on the Swin3D backbone: registry name "OffsetKeypointSwin3D".
 
 Contract of the reference class (pointcept/models/offset_keypoint_swin3d.py:5-130): constructor keywords
 `backbone_conf, num_keypoints, hidden_dim`; state_dict = `backbone.*` + `head.{0,1,3}.*`; `coord_feat` is built from
