@@ -161,35 +161,63 @@ __global__ __launch_bounds__(SWB_WAVES * 64) void swin_attn_bwd_kernel(
       delta = fmaf(p, dp, delta);
     }
     delta = gsum(delta, G);
-    // sweep 3: gradients
+    // sweep 3: gradients.  The table gradients are scatter-adds of D-vectors to rows chosen by data.  Issued by the
+    // pair's own lane (D atomics to one row, every lane a different row) each wave instruction touched 64 cache lines
+    // for 256 useful bytes; instead the lanes of a query group take the pairs of the current sweep step in turn, 16
+    // lanes per pair, lane ch adding channel ch (and ch + 16): one 64-byte piece of one row per 16 lanes.
     float dqa[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) dqa[d] = 0.f;
-    for (int j = gl; j < m; j += G) {
-      const float p = P[j];
-      const float ds = p * (DP[j] - delta);
+    const int ch = gl & 15, sub = gl >> 4, nsub = G >> 4;
+    float qmine[(D + 15) / 16], domine[(D + 15) / 16];
+#pragma unroll
+    for (int u = 0; u < (D + 15) / 16; ++u) {
+      qmine[u] = 0.f; domine[u] = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+        if (d == ch + 16 * u) { qmine[u] = qi[d]; domine[u] = doi[d]; }
+    }
+    const int lane0 = lane & ~(G - 1);             // first lane of this query group
+    for (int jb = 0; jb < m; jb += G) {            // group-uniform sweep step: lane gl holds pair (i, jb + gl)
+      const int j = jb + gl;
+      const bool mine_ok = live && j < m;
+      const int jj = j < m ? j : m - 1;
+      const float p = mine_ok ? P[jj] : 0.f;
+      const float ds = mine_ok ? p * (DP[jj] - delta) : 0.f;
       float kj[D], dkj[D];
-      ldrow<D>(sK + j * RS, kj);
+      ldrow<D>(sK + jj * RS, kj);
 #pragma unroll
       for (int d = 0; d < D; ++d) { dqa[d] = fmaf(ds, kj[d], dqa[d]); dkj[d] = ds * qi[d]; }
 #pragma unroll
       for (int c = 0; c < S; ++c) {
-        const size_t r = trow(ci, j, c);
+        const size_t r = trow(ci, jj, c);
         float tk[D], tq[D];
         ldrow<D>(kt + r, tk);
         ldrow<D>(qt + r, tq);
 #pragma unroll
         for (int d = 0; d < D; ++d) { dqa[d] = fmaf(ds, tk[d], dqa[d]); dkj[d] = fmaf(ds, tq[d], dkj[d]); }
-        if (live) {
+        // cooperative scatter of this step's pairs: sub-group `sub` serves source lanes sub, sub + nsub, ...
+        const unsigned roff = (unsigned)r;
+        for (int s0 = 0; s0 < G; s0 += nsub) {
+          const int src = s0 + sub;
+          const unsigned rs = __shfl(roff, lane0 + src);
+          const float dss = __shfl(ds, lane0 + src);
+          const float ps = __shfl(p, lane0 + src);
+          const int js = jb + src;
+          if (js < m && (dss != 0.f || ps != 0.f)) {
 #pragma unroll
-          for (int d = 0; d < D; ++d) {
-            atomicAdd(dkt + r + d, ds * qi[d]);
-            atomicAdd(dqt + r + d, ds * kj[d]);
-            atomicAdd(dvt + r + d, p * doi[d]);
+            for (int u = 0; u < (D + 15) / 16; ++u) {
+              const int d = ch + 16 * u;
+              if (d < D) {
+                atomicAdd(dkt + rs + d, dss * qmine[u]);
+                atomicAdd(dqt + rs + d, dss * sK[js * RS + d]);
+                atomicAdd(dvt + rs + d, ps * domine[u]);
+              }
+            }
           }
         }
       }
-      if (live) {
+      if (mine_ok) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
           atomicAdd(sdK + j * D + d, dkj[d]);

@@ -52,11 +52,53 @@ def bench_model(n, dev):
                       "finite": bool(torch.isfinite(y).all().item())}))
 
 
+def bench_train(n, dev):
+    """Training step (forward + backward + FusedAdamW) of the fork's Swin3D offset model
+    (configs/my_dataset/offset_keypoint_swin3d.py: quant 50, XYZ_RGB, 4 levels), one scene of n points, fp32."""
+    from ptv3_hip import configs
+    from ptv3_hip.optim import FusedAdamW
+    from pointcept.models import build_model
+    rng = np.random.default_rng(0)
+    extent = int((n / 1.2) ** 0.5)
+    g = surface(n, extent, 1)[:, 1:].astype(np.int64)
+    n = len(g)
+    batch = {"coord": torch.from_numpy(((g + rng.random(g.shape)) * 0.02).astype(np.float32)).to(dev),
+             "grid_coord": torch.from_numpy(g).to(dev),
+             "feat": torch.from_numpy(np.clip(rng.normal(size=(n, 4)) * 0.5, -1, 1).astype(np.float32)).to(dev),
+             "offset": torch.tensor([n], device=dev),
+             "target": torch.from_numpy(np.concatenate([rng.normal(size=(n, 6, 3)) * 0.3, rng.random((n, 6, 1)) > 0.5],
+                                                       -1).astype(np.float32)).to(dev)}
+    torch.manual_seed(0)
+    model = build_model(configs.OFFSET_SWIN3D_CFG).to(dev).train()
+    opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+
+    def step():
+        opt.zero_grad()
+        loss = model(dict(batch))["loss"]
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        loss = step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    print(json.dumps({"model": "OffsetKeypointSwin3D (fork config, quant 50, XYZ_RGB) train step", "points": n,
+                      "dtype": "float32", "ms_per_step": round(ms, 1), "Mpoints_per_s": round(n / ms / 1e3, 3),
+                      "loss": round(float(loss), 4)}))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
     dev = torch.device("cuda:0")
     if len(sys.argv) > 2 and sys.argv[2] == "model":
         return bench_model(n, dev)
+    if len(sys.argv) > 2 and sys.argv[2] == "train":
+        return bench_train(n, dev)
     extent = int((n / 1.2) ** 0.5)
     coords = torch.from_numpy(surface(n, extent, 0)).to(dev)
     n = coords.shape[0]
