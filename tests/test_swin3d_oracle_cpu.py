@@ -104,3 +104,30 @@ def test_index_range_stays_inside_the_tables():
     d = cr[:m, None, :3] - cr[None, :m, :3]
     assert np.floor(d + 20).min() >= 0 and np.floor(d + 20).max() <= 39
     assert np.floor(np.float32(8.0) - np.float32(-8.0) + np.float32(16)) == 32     # white vs black: one past the table
+
+
+def test_whole_model_oracle_is_equivariant_to_the_order_of_the_input_points():
+    """Swin3DOracle.forward (voxel averaging, stem, attention stages, KNN down / up-sampling, classifier, slice back):
+    relabelling the input points permutes the output rows and changes nothing else - voxels are numbered by sorted
+    coordinate, never by input order.  (A sanity check of the restatement itself; the HIP model is compared with it in
+    tests/test_hip_swin3d.py.)"""
+    import torch
+    from ptv3_hip import configs
+    from pointcept.models import build_model
+    cfg = dict(configs.TINY_SWIN3D_CFG, depths=[1, 1, 1])
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    sd = {k: v.numpy() for k, v in model.state_dict().items()}
+    rng = np.random.default_rng(5)
+    g = _voxels(700, 16, 9)[:, 1:].astype(np.int64)
+    n = len(g)
+    data = {"coord": ((g + rng.random(g.shape)) * 0.02).astype(np.float32), "grid_coord": g,
+            "feat": rng.normal(size=(n, 9)).astype(np.float32),
+            "coord_feat": rng.uniform(-1, 1, (n, 6)).astype(np.float32), "offset": np.array([n], np.int64)}
+    oracle = O.Swin3DOracle(sd, cfg)
+    base = oracle.forward(data)
+    perm = rng.permutation(n)
+    shuffled = {k: (v[perm] if k != "offset" else v) for k, v in data.items()}
+    again = oracle.forward(shuffled)
+    assert base.shape == (n, 13) and np.isfinite(base).all()
+    np.testing.assert_allclose(again, base[perm], rtol=1e-5, atol=1e-5)
