@@ -22,8 +22,19 @@ __device__ __forceinline__ void slab_sum_body(const float* __restrict__ slab, in
   const int c = threadIdx.x & (SS_COLS - 1), z0 = threadIdx.x / SS_COLS;
   const long long j = col_block * SS_COLS + c;
   float s = 0.f;
-  if (j < n)
-    for (int z = z0; z < nslab; z += SS_LANES) s += slab[(long long)z * n + j];
+  if (j < n) {
+    // eight loads in flight per lane, added in slab order (the sum is the same chain as a plain loop: one load per
+    // trip made every addition wait a full memory round trip - 59 us for the reductions of one block backward)
+    int z = z0;
+    for (; z + 7 * SS_LANES < nslab; z += 8 * SS_LANES) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slab[(long long)(z + u * SS_LANES) * n + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < nslab; z += SS_LANES) s += slab[(long long)z * n + j];
+  }
   red[z0][c] = s;
   __syncthreads();
   if (z0 == 0 && j < n) {
