@@ -336,6 +336,34 @@ def semseg_lidar_workload(device, args, world):
             "forwards_in_flight": 2, "stage_points": pts}
 
 
+def train_step_workload(device, args):
+    """BASELINE configs[3]'s per-GPU share beside the headline: one training step (forward + backward + fused AdamW) of the
+    fork config on one 100k-point scene, bf16 activations, fp32 masters, drop_path 0.3 - what `--mode train` times."""
+    import ptv3_scenes as S
+    from ptv3_hip.optim import FusedAdamW
+    model, _, _ = build_model(device, "offset")
+    model.backbone.compute_dtype = torch.bfloat16
+    model.train()
+    groups = [dict(params=[p for n, p in model.named_parameters() if "block" in n], lr=2e-4),
+              dict(params=[p for n, p in model.named_parameters() if "block" not in n])]
+    opt = FusedAdamW(groups, lr=2e-3, weight_decay=5e-3, shadow_dtype=torch.bfloat16)
+    batch = {k: v.to(device) for k, v in S.collate([make_scene(100000, "surface", 1000)], with_target=6).items()}
+    last = {}
+
+    def step():
+        opt.zero_grad()
+        out = model(batch)
+        out["loss"].backward()
+        opt.step()
+        last["loss"] = out["loss"]
+
+    steps = 10
+    elapsed = timed_steps(step, steps, 3, 1, device)
+    return {"workload": "OffsetKeypointPTv3 (fork config, 46.2M params) train step: forward + backward + fused AdamW, "
+                        "1 x 100000-point scene, bf16 activations, drop_path 0.3", "value": round(1e5 * steps / elapsed / 1e6, 4),
+            "unit": "Mpoints/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "final_loss": float(last["loss"].item())}
+
+
 def swin3d_workload(device, points=300000):
     """BASELINE configs[4] beside the headline: "Swin3D-v1m1" (Swin3D-S, the S3DIS config: 9 input channels, colour + normal
     signals, 5^3 / 7^3-voxel windows with cRSE tables) forward on one room-like scene.  fp32, random weights;
@@ -563,6 +591,8 @@ def run(args):
         extra = {"semseg_lidar_120k": semseg_lidar_workload(device, args, world)}
         torch.cuda.empty_cache()
         extra["swin3d_s3dis_300k"] = swin3d_workload(device)
+        torch.cuda.empty_cache()
+        extra["train_step_100k"] = train_step_workload(device, args)
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
