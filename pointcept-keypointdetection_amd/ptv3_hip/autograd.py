@@ -531,30 +531,28 @@ class BlockNativeFn(Function):
         taped = any(ctx.needs_input_grad)      # the transposed weights are only read by the backward
         ws = [_transposed(_weights(w, dt), kvol if i == 0 else 1) if taped else (_weights(w, dt)[0], None)
               for i, w in enumerate((conv_w, lin_w, qkv_w, proj_w, fc1_w, fc2_w))]
-        b = BlockTrain()
-        b.n, b.n_pad, b.c, b.hidden, b.heads, b.patch, b.kvol = n, wo.shape[0], c, hidden, int(heads), int(patch), kvol
-        b.num_windows = 0 if cu is None else cu.numel() - 1
-        b.dtype, b.scale, b.eps, b.sum_len_sq = ops._dt(feat), float(scale), float(eps), 0.0
-        b.nbr, b.row_order, b.win_order, b.win_inverse, b.cu_seqlens = _ptr(nbr), _ptr(row_order), _ptr(wo), _ptr(wi), _ptr(cu)
-        b.feat, b.conv_feat = feat.data_ptr(), _ptr(xin)
-        (b.w_conv, b.wt_conv), (b.w_lin, b.wt_lin), (b.w_qkv, b.wt_qkv), (b.w_proj, b.wt_proj), (b.w_fc1, b.wt_fc1), \
-            (b.w_fc2, b.wt_fc2) = [(_ptr(w), _ptr(t)) for w, t in ws]
-        for name, p in (("b_conv", conv_b), ("b_lin", lin_b), ("b_qkv", qkv_b), ("b_proj", proj_b), ("b_fc1", fc1_b),
-                        ("b_fc2", fc2_b), ("g0", ln0_g), ("b0", ln0_b), ("g1", n1_g), ("b1", n1_b), ("g2", n2_g),
-                        ("b2", n2_b)):
-            setattr(b, name, _f32_ptr(p, name))
         for name, u in (("mask1", mask1), ("mask2", mask2)):    # uniform draws per point (fp32), see drop_factor
             if u is not None and (u.dtype != torch.float32 or u.numel() != n or not u.is_contiguous()):
                 raise TypeError(f"BlockNativeFn: {name} must be a contiguous fp32 draw per point")
-        b.mask1, b.mask2, b.keep1, b.keep2 = _ptr(mask1), _ptr(mask2), float(keep1), float(keep2)
-        # activations the backward needs: one allocation, carved into (n, c) x 9, (n, 3c), (n, hidden) x 2
+        # activations the backward needs: ONE allocation; the descriptor gets addresses inside it (only `out`, which
+        # leaves this Function, becomes a tensor view)
+        esz = feat.element_size()
         flat = torch.empty(n * (9 * c + 3 * c + 2 * hidden), dtype=dt, device=dev)
-        views, at = {}, 0
-        for name, width in (("c1", c), ("c2", c), ("f1", c), ("t3", c), ("a", c), ("f2", c), ("t5", c), ("out", c),
-                            ("qkv", 3 * c), ("h0", hidden), ("h", hidden)):
-            views[name] = flat[at:at + n * width].view(n, width)
-            setattr(b, name, views[name].data_ptr())
-            at += n * width
+        base = flat.data_ptr()
+        nc, nh = n * c * esz, n * hidden * esz
+        act = [base + i * nc for i in range(8)]                                  # c1 c2 f1 t3 a f2 t5 out
+        qkv_p, h0_p, h_p = base + 8 * nc, base + 11 * nc, base + 11 * nc + nh
+        out = flat[7 * n * c:8 * n * c].view(n, c)
+        vec = [_f32_ptr(p, nm) for nm, p in (("b_conv", conv_b), ("b_lin", lin_b), ("b_qkv", qkv_b), ("b_proj", proj_b),
+                                            ("b_fc1", fc1_b), ("b_fc2", fc2_b), ("g0", ln0_g), ("b0", ln0_b),
+                                            ("g1", n1_g), ("b1", n1_b), ("g2", n2_g), ("b2", n2_b))]
+        wp = [_ptr(w) for w, _ in ws] + [_ptr(t) for _, t in ws]
+        # positional construction in the field order of struct ptv3_block_train (one call instead of ~70 attribute sets)
+        b = BlockTrain(n, wo.shape[0], c, hidden, int(heads), int(patch), kvol, 0 if cu is None else cu.numel() - 1,
+                       ops._dt(feat), 0, float(scale), float(eps), float(keep1), float(keep2), 0.0,
+                       _ptr(nbr), _ptr(row_order), _ptr(wo), _ptr(wi), _ptr(cu), feat.data_ptr(), _ptr(xin),
+                       *wp, *vec, _ptr(mask1), _ptr(mask2),
+                       act[0], act[1], act[2], act[3], qkv_p, act[4], act[5], act[6], h0_p, h_p, act[7])
         nb = lib.ptv3_block_train_workspace_bytes(ctypes.byref(b), 0)
         wsb = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
         b.workspace, b.workspace_bytes = wsb.data_ptr(), nb
@@ -563,7 +561,7 @@ class BlockNativeFn(Function):
         ctx.block, ctx.flat, ctx.keep = b, flat, (ws, conv_w, (conv_b, lin_b, qkv_b, proj_b, fc1_b, fc2_b, ln0_g, ln0_b,
                                                                 n1_g, n1_b, n2_g, n2_b))
         ctx.shapes = (n, c, hidden, kvol, conv_w.shape)
-        return views["out"]
+        return out
 
     @staticmethod
     def backward(ctx, dout):
