@@ -17,6 +17,7 @@
 // output-channel dimension instead, i.e. from the tiled GEMM kernel (measured C=256, M=1388: 299 us fused vs
 // 40 us unfused), so wider blocks keep the unfused kernels.
 #include "common.h"
+#include "block_args.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -24,63 +25,6 @@
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
-
-struct HeadArgs {
-  const void* x; const float* slab; int splits; const float* conv_bias;  // x XOR slab
-  const void* shortcut;
-  const float *g0, *b0, *g1, *b1;
-  const void* wqkv; const float* bqkv;
-  void* f1; void* qkv;
-  int64_t m; float eps;
-};
-
-struct TailArgs {
-  const void* attn; const void* f1;
-  const void* wproj; const float* bproj;
-  const float *g2, *b2;
-  const void* w1; const float* bias1; const void* w2; const float* bias2;
-  void* out;
-  int64_t m; int hidden; float eps;
-};
-
-__device__ __forceinline__ float groups_sum(float x) {
-  x += __shfl_xor(x, 16, 64);
-  return x + __shfl_xor(x, 32, 64);
-}
-
-// the B fragment of K-chunk `kc` from accumulator-layout tiles t[] (already rounded to T)
-template <typename T, int NT> struct ChainFrag;
-template <int NT> struct ChainFrag<float, NT> {
-  static constexpr int NKC = NT;  // 16-channel chunks
-  static __device__ __forceinline__ f32x4 get(const f32x4* t, int kc) { return t[kc]; }
-};
-template <int NT> struct ChainFrag<__bf16, NT> {
-  static constexpr int NKC = NT / 2;  // 32-channel chunks = two tiles
-  static __device__ __forceinline__ s16x8 get(const f32x4* t, int kc) {
-    s16x4 lo = pack4<__bf16>(t[2 * kc][0], t[2 * kc][1], t[2 * kc][2], t[2 * kc][3]);
-    s16x4 hi = pack4<__bf16>(t[2 * kc + 1][0], t[2 * kc + 1][1], t[2 * kc + 1][2], t[2 * kc + 1][3]);
-    return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  }
-};
-
-template <typename T> __device__ __forceinline__ float round_to(float v);
-template <> __device__ __forceinline__ float round_to<float>(float v) { return v; }
-template <> __device__ __forceinline__ float round_to<__bf16>(float v) { return (float)(__bf16)v; }
-
-// LayerNorm over the C = 16*NT channels of the lane's point; values in accumulator layout v[j][r] = channel 16j+4g+r
-template <int NT>
-__device__ __forceinline__ void row_norm(const f32x4* v, float eps, float& mean, float& rstd) {
-  float s = 0.f;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-  mean = groups_sum(s) * (1.0f / (16 * NT));
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { float d = v[j][r] - mean; q += d * d; }
-  rstd = rsqrtf(groups_sum(q) * (1.0f / (16 * NT)) + eps);
-}
 
 template <typename T> struct WPad { static constexpr int V = 16 / sizeof(T); };
 
@@ -819,9 +763,16 @@ static int64_t coop_max_rows(int c) {
   return lim[i];
 }
 
+// 3: the weight-streaming variant of block_wide.hip (its buffer stores address rows with 32-bit byte offsets)
+static bool wide_rows(int c, int hidden, int dtype, int64_t m) {
+  return wide_capable(c, hidden, dtype) && m >= wide_min_rows(c) &&
+         m * 3 * c * (dtype == PTV3_F32 ? 4 : 2) < ((int64_t)1 << 31) - (1 << 20);
+}
+
 extern "C" int ptv3_block_fusable(int c, int hidden, int dtype, int64_t m) {
   if (hidden <= 0 || hidden % 64 != 0 || (dtype != PTV3_F32 && dtype != PTV3_BF16)) return 0;
   if (c == 32 || c == 64) return 1;
+  if (wide_rows(c, hidden, dtype, m)) return 3;
   if ((c == 128 || c == 256 || c == 512) && hidden == 4 * c && m <= coop_max_rows(c) &&
       coop_tail_lds(c, hidden, dtype == PTV3_F32 ? 4 : 2) <= 160 * 1024)
     return 2;
@@ -914,7 +865,9 @@ extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, con
                                const void* shortcut, const float* g0, const float* b0, const float* g1,
                                const float* b1, const void* wqkv, const float* bqkv, void* f1, void* qkv, int64_t m,
                                int c, float eps, int dtype, void* stream) {
-  const int mode = ptv3_block_fusable(c, 4 * c, dtype, 0);  // m = 0: capability only, the row limits are the caller's policy
+  // m = 0: capability only, the row limits of the cooperative variant are the caller's policy; the streaming
+  // variant takes over from its own row threshold
+  const int mode = wide_rows(c, 4 * c, dtype, m) && x != nullptr ? 3 : ptv3_block_fusable(c, 4 * c, dtype, 0);
   PTV3_REQUIRE(mode != 0, "block_head: c=%d not fusable", c);
   PTV3_REQUIRE((x != nullptr) != (slab != nullptr), "block_head: give the conv output OR its split-K slabs");
   PTV3_REQUIRE(slab == nullptr || (splits >= 1 && conv_bias != nullptr), "block_head: slabs need splits and the conv bias");
@@ -924,8 +877,10 @@ extern "C" int ptv3_block_head(const void* x, const float* slab, int splits, con
   HeadArgs a{x, slab, splits, conv_bias, shortcut, g0, b0, g1, b1, wqkv, bqkv, f1, qkv, m, eps};
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * 3 * c, ((double)m * c * 6 + 3.0 * c * c) * esz, nullptr, 0, 0.0);
-  prof_kernel(prof, mode == 1 ? PK_BLOCK_HEAD : PK_BLOCK_HEAD_COOP);
-  if (mode == 1) {
+  prof_kernel(prof, mode == 1 ? PK_BLOCK_HEAD : mode == 3 ? PK_BLOCK_HEAD_WIDE : PK_BLOCK_HEAD_COOP);
+  if (mode == 3) {
+    launch_block_head_wide(a, c, dtype, s);
+  } else if (mode == 1) {
     const int64_t nblocks = cdiv(m, 64);
     const size_t wb = (size_t)3 * c * (c + 16 / esz) * esz + (size_t)8 * c * sizeof(float);  // weights + vectors
     const dim3 grid_l((unsigned)std::min<int64_t>(nblocks, 4 * 256)), block(256);
@@ -948,7 +903,7 @@ extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wpr
                                const float* g2, const float* b2, const void* w1, const float* bias1, const void* w2,
                                const float* bias2, void* out, int64_t m, int c, int hidden, float eps, int dtype,
                                void* stream) {
-  const int mode = ptv3_block_fusable(c, hidden, dtype, 0);
+  const int mode = wide_rows(c, hidden, dtype, m) ? 3 : ptv3_block_fusable(c, hidden, dtype, 0);
   PTV3_REQUIRE(mode != 0, "block_tail: c=%d / hidden=%d not fusable", c, hidden);
   PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "block_tail: bad dtype");
   if (m == 0) return PTV3_OK;
@@ -957,8 +912,10 @@ extern "C" int ptv3_block_tail(const void* attn, const void* f1, const void* wpr
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * (c + 2.0 * hidden),
                               ((double)m * c * 3 + (double)c * c + 2.0 * c * hidden) * esz, nullptr, 0, 0.0);
-  prof_kernel(prof, mode == 1 ? PK_BLOCK_TAIL : PK_BLOCK_TAIL_COOP);
-  if (mode == 1) {
+  prof_kernel(prof, mode == 1 ? PK_BLOCK_TAIL : mode == 3 ? PK_BLOCK_TAIL_WIDE : PK_BLOCK_TAIL_COOP);
+  if (mode == 3) {
+    launch_block_tail_wide(a, c, dtype, s);
+  } else if (mode == 1) {
     TAIL_LAUNCH(a)
   } else {
     COOP_LAUNCH(launch_tail_coop, a)

@@ -308,6 +308,45 @@ def test_fused_block_halves_vs_torch(dev, c, m):
             assert (f1s.cpu() - f1_ref).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("c,m", [(128, 24576 + 77), (256, 24576 + 1), (256, 24576 + 127)])
+def test_wide_block_halves_vs_torch(dev, c, m):
+    """The weight-streaming variant of ptv3_block_head / ptv3_block_tail (csrc/block_wide.hip: c in {128, 256} from
+    24 576 rows on; natural weight layout; ragged last workgroup) against plain torch fp32 of the same chain, and - in
+    bf16 - against the launches it replaces (LayerNorm + tiled GEMMs) on the same bf16 inputs."""
+    from ptv3_hip import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(c + m)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    x, shortcut, attn = rnd(m, c), rnd(m, c), rnd(m, c)
+    g0, b0, g1, b1, g2, b2 = (rnd(c) for _ in range(6))
+    wqkv, bqkv = rnd(3 * c, c) / c ** 0.5, rnd(3 * c)
+    wproj, bproj = rnd(c, c) / c ** 0.5, rnd(c)
+    w1, bias1 = rnd(4 * c, c) / c ** 0.5, rnd(4 * c)
+    w2, bias2 = rnd(c, 4 * c) / (4 * c) ** 0.5, rnd(c)
+    f1_ref = F.layer_norm(x, (c,), g0, b0, 1e-5) + shortcut
+    qkv_ref = F.linear(F.layer_norm(f1_ref, (c,), g1, b1, 1e-5), wqkv, bqkv)
+    f2 = F.linear(attn, wproj, bproj) + f1_ref
+    out_ref = f2 + F.linear(F.gelu(F.linear(F.layer_norm(f2, (c,), g2, b2, 1e-5), w1, bias1)), w2, bias2)
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    for dtype in (torch.float32, torch.bfloat16):
+        cv = lambda t: d(t).to(dtype).contiguous()  # noqa: E731
+        assert ops.block_fusable(c, 4 * c, dtype, m) == 3
+        f1, qkv = ops.block_head(cv(x), None, 0, None, cv(shortcut), d(g0), d(b0), d(g1), d(b1), cv(wqkv), d(bqkv), 1e-5)
+        out = ops.block_tail(cv(attn), cv(f1_ref), cv(wproj), d(bproj), d(g2), d(b2), cv(w1), d(bias1), cv(w2), d(bias2), 1e-5)
+        for got, ref in ((f1, f1_ref), (qkv, qkv_ref), (out, out_ref)):
+            # bf16: inputs, weights and three intermediate activations are rounded to 8 significant bits
+            tol = FP32_TOL if dtype == torch.float32 else 8 * 2.0 ** -8 * max(1.0, ref.abs().max().item())
+            assert (got.float().cpu() - ref).abs().max().item() < tol
+        if dtype == torch.bfloat16:
+            f1u, t3 = ops.layernorm(cv(x), d(g0), d(b0), 1e-5, res=cv(shortcut), gamma2=d(g1), beta2=d(b1))
+            qkvu = ops.gemm(t3, cv(wqkv), bias=d(bqkv))
+            f2u = ops.gemm(cv(attn), cv(wproj), bias=d(bproj), res=cv(f1_ref))
+            t6 = ops.gemm(ops.layernorm(f2u, d(g2), d(b2), 1e-5), cv(w1), bias=d(bias1), act=ops.ACT_GELU)
+            outu = ops.gemm(t6, cv(w2), bias=d(bias2), res=f2u)
+            for got, ref in ((f1, f1u), (qkv, qkvu), (out, outu)):   # a few bf16 steps of the value (summation order, GELU form)
+                assert (got.float() - ref.float()).abs().max().item() <= 4 * 2.0 ** -8 * max(1.0, ref.float().abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------------
