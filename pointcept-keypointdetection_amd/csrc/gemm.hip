@@ -10,8 +10,10 @@
 // Reference semantics: include/ptv3_hip.h (ptv3_gemm).
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include "common.h"
 #include "profile.h"
+#include "block_args.h"
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -25,6 +27,7 @@ struct GemmArgs {
   const float* bias; const float* bn_scale; const float* bn_shift;
   float* slab;  // split-K partial sums [splits][m][cout] fp32 (NULL: direct epilogue)
   int64_t m; int cin; int cout; int kvol; int act; int cin_shift; int steps_per_split;
+  int64_t x_bytes;   // size of x in bytes when it is known to be < 2^31 (buffer-descriptor addressing), else 0
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -396,7 +399,7 @@ constexpr int GB_THREADS = 256;
 constexpr int GB_MAX_KVOL = 27;
 constexpr int GB_MAX_STEPS = 256;   // K steps a tile can list for tap skipping (27 taps x 512 channels / 64 = 216)
 
-template <typename T, int WM, int WN, int BN, bool GATHER>
+template <typename T, int WM, int WN, int BN, bool GATHER, bool BUF>
 __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
@@ -492,6 +495,16 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
   // wait with s_waitcnt vmcnt(0) - for the younger stage too - where a counted wait leaves that stage in flight.
   FR rxa[X_LOADS], rwa[W_LOADS], rxb[X_LOADS], rwb[W_LOADS];
   unsigned oka = 0, okb = 0;   // validity bits of the two stages: bit u = x chunk u, bit 8 + u = w chunk u
+  // BUF: operands addressed through buffer descriptors (both smaller than 4 GB: the launcher checks).  An element that
+  // does not exist - a missing neighbour (three quarters of a LiDAR sheet's 27 taps), a row, channel or K index past
+  // the end - gets an offset beyond num_records: the load returns zeros WITHOUT a memory access, and the stage goes to
+  // LDS as it stands.  (The pointer form reads a dummy row instead and zeroes it on the way to LDS: the same number of
+  // cache requests as a dense tile, on a kernel bound by its operand traffic.)
+  __amdgpu_buffer_rsrc_t xrs, wrs;
+  if constexpr (BUF) {
+    xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)a.x_bytes, 0x00020000);
+    wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(w), 0, (int)((int64_t)a.cout * ktot * (int)sizeof(T)), 0x00020000);
+  }
   auto issue = [&](int step, FR (&rx)[X_LOADS], FR (&rw)[W_LOADS], unsigned& ok) {
     const int kk = step * BK + E * c;
     const bool kin = kk < ktot;
@@ -507,15 +520,25 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
       int64_t src = xrow[u];
       if constexpr (GATHER) src = sNbr[(r0 + 32 * u) * a.kvol + d];
       const bool v = kin && src >= 0;
-      ok |= (unsigned)v << u;
-      rx[u] = *reinterpret_cast<const FR*>(x + (v ? src : 0) * a.cin + cc);
+      if constexpr (BUF) {
+        const unsigned off = v ? (unsigned)((src * a.cin + cc) * (int)sizeof(T)) : 0xFFFFFFF0u;
+        rx[u] = __builtin_bit_cast(FR, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+      } else {
+        ok |= (unsigned)v << u;
+        rx[u] = *reinterpret_cast<const FR*>(x + (v ? src : 0) * a.cin + cc);
+      }
     }
 #pragma unroll
     for (int u = 0; u < W_LOADS; ++u) {
       const int o = n0 + r0 + 32 * u;
       const bool v = kin && o < a.cout;
-      ok |= (unsigned)v << (8 + u);
-      rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)(v ? o : 0) * ktot + kks);
+      if constexpr (BUF) {
+        const unsigned off = v ? (unsigned)(((int64_t)o * ktot + kks) * (int)sizeof(T)) : 0xFFFFFFF0u;
+        rw[u] = __builtin_bit_cast(FR, __builtin_amdgcn_raw_buffer_load_b128(wrs, off, 0, 0));
+      } else {
+        ok |= (unsigned)v << (8 + u);
+        rw[u] = *reinterpret_cast<const FR*>(w + (int64_t)(v ? o : 0) * ktot + kks);
+      }
     }
   };
   auto stash = [&](int buf, const FR (&rx)[X_LOADS], const FR (&rw)[W_LOADS], unsigned ok) {
@@ -523,13 +546,13 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
     for (int u = 0; u < X_LOADS; ++u) {
       const int r = r0 + 32 * u;
       *reinterpret_cast<FR*>(sX + ((size_t)buf * GB_BM + r) * BK + E * (c ^ ((r >> 1) & 7))) =
-          ((ok >> u) & 1u) ? rx[u] : F::zero();
+          (BUF || ((ok >> u) & 1u)) ? rx[u] : F::zero();
     }
 #pragma unroll
     for (int u = 0; u < W_LOADS; ++u) {
       const int r = r0 + 32 * u;
       *reinterpret_cast<FR*>(sW + ((size_t)buf * BN + r) * BK + E * (c ^ ((r >> 1) & 7))) =
-          ((ok >> (8 + u)) & 1u) ? rw[u] : F::zero();
+          (BUF || ((ok >> (8 + u)) & 1u)) ? rw[u] : F::zero();
     }
   };
 
@@ -625,6 +648,195 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
       epilogue_store<T>(a, orow, ch0, v);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 256-point tile for the sparse convolutions of the chip-filling deep levels (LiDAR-like scans: C = 256 / 512 with
+// 10^4..10^5 sites).  gemm_big_kernel above moves 32 KB of operands per 2.1 MFLOP K-step through registers into LDS
+// and sits at ~690 dense-equivalent TFLOP/s whatever the tap occupancy: the LDS STORE path (ds_write_b128: ~79 B/clk
+// per CU) and the operand stream L2 -> CU bound it, not the matrix core (27 % busy).  Here:
+//   * 256 points x 256 (128) channels per 8-wave workgroup, a wave holds 128 x 64 (64 x 64): 64 (48) KB of operands
+//     per 8.4 (4.2) MFLOP K-step - half the bytes per flop;
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write; the
+//     copies of step s+1 are issued right after the barrier of step s and land under its matrix-core work;
+//   * both operands are addressed through buffer descriptors: a missing neighbour (or a channel row past cout) is an
+//     offset beyond num_records, which the DMA turns into zeros in LDS without a memory access (probe:
+//     tools/probes/lds_dma_oob.hip) - no validity bits, no selects, no dummy reads;
+//   * LDS image as above (128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7)), the swizzle applied to the SOURCE
+//     chunk a lane fetches, the DMA destination being lane-linear;
+//   * fragments are read one group (4 point fragments x the 4 channel fragments of a K half-step = 16 matrix-core
+//     steps) ahead of their use.
+// Same K order, epilogue and results as the other two kernels (fp32: bitwise).  cin must be a multiple of the 64 | 32
+// channels of a K-step (one tap per step).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int GC_BM = 256;
+constexpr int GC_THREADS = 512;
+
+template <int N, int END, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+  if constexpr (N < END) {
+    f(std::integral_constant<int, N>{});
+    static_for<N + 1, END>(f);
+  }
+}
+
+#define PTV3_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <typename T, int BN>
+__global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  constexpr int E = F::E;
+  constexpr int BK = 2 * F::KC;
+  constexpr int WN = BN / 64, WM = 8 / WN;       // waves across channels / points
+  constexpr int MI = GC_BM / (16 * WM), NJ = 4;  // accumulator fragments per wave: MI x NJ (8 x 4 | 4 x 4)
+  constexpr int STG = (GC_BM + BN) * 128;        // bytes per stage
+  constexpr int XQ = GC_BM / 64, WQ = BN / 64;   // copies per wave and step
+  constexpr int NGRP = 2 * (MI / 4);             // fragment groups per K-step
+  extern __shared__ __attribute__((aligned(16))) char gc_smem[];
+  char* stg = gc_smem;                                                   // [2][STG]
+  int32_t* sNbr = reinterpret_cast<int32_t*>(gc_smem + 2 * STG);       // [256][kvol <= 27]
+  float* sEpi = reinterpret_cast<float*>(sNbr + GC_BM * GB_MAX_KVOL);  // [3][BN]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, g = lane >> 4;
+  const int wr = wave / WN, wc = wave % WN;
+  const unsigned ntn = (a.cout + BN - 1) / BN;
+  const unsigned logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t row0 = (int64_t)(logical / ntn) * GC_BM;
+  const int n0 = (int)(logical % ntn) * BN;
+  const int ktot = a.kvol * a.cin;
+  const int nsteps = ktot / BK;
+
+  for (int e = tid; e < GC_BM * a.kvol; e += GC_THREADS) {
+    const int pr = e / a.kvol, d = e - pr * a.kvol;
+    const int64_t r = row0 + pr;
+    sNbr[e] = r < a.m ? a.nbr[(a.row_order ? (int64_t)a.row_order[r] : r) * a.kvol + d] : -1;
+  }
+  park_epi(a, sEpi, BN, n0, tid, GC_THREADS);
+
+  const __amdgpu_buffer_rsrc_t xrs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.w), 0, (int)((int64_t)a.cout * ktot * (int)sizeof(T)), 0x00020000);
+  // copy q = wave + 8 i covers rows 8q .. 8q+7: lane -> (row 8q + lane / 8, LDS chunk lane % 8)
+  const int rr = lane >> 3, cch = lane & 7;
+  int xnb[XQ];          // LDS index of the lane's row in the neighbour table (x kvol)
+  unsigned xcol[XQ];    // byte offset of the source chunk inside the step's 128 bytes
+  unsigned woff[WQ];    // byte offset of (channel row, source chunk) in w, or out of range
+#pragma unroll
+  for (int i = 0; i < XQ; ++i) {
+    const int r = 8 * (wave + 8 * i) + rr;
+    xnb[i] = r * a.kvol;
+    xcol[i] = (unsigned)((cch ^ ((r >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < WQ; ++i) {
+    const int r = 8 * (wave + 8 * i) + rr;
+    const int o = n0 + r;
+    woff[i] = o < a.cout ? (unsigned)(((int64_t)o * ktot) * (int)sizeof(T)) + (unsigned)((cch ^ ((r >> 1) & 7)) * 16) : 0xFFFFFFF0u;
+  }
+  const unsigned row_bytes = (unsigned)(a.cin * (int)sizeof(T));
+  auto issue = [&](int step) {
+    char* buf = stg + (step & 1) * STG;
+    const int k0 = step * BK;
+    const int d = a.cin_shift >= 0 ? (k0 >> a.cin_shift) : (k0 / a.cin);
+    const unsigned kb = (unsigned)((k0 - d * a.cin) * (int)sizeof(T));   // byte offset of the step's channels in a row of x
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+      const int src = sNbr[xnb[i] + d];
+      const unsigned off = src >= 0 ? (unsigned)src * row_bytes + kb + xcol[i] : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, PTV3_LDS_PTR(buf + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+    }
+    const unsigned kw = (unsigned)(k0 * (int)sizeof(T));
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+      const unsigned off = woff[i] == 0xFFFFFFF0u ? woff[i] : woff[i] + kw;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, PTV3_LDS_PTR(buf + GC_BM * 128 + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[MI][NJ];
+#pragma unroll
+  for (int m = 0; m < MI; ++m)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[m][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment of row r, K chunk (ks, g) of an operand image
+  auto frag = [&](const char* img, int r, int ks) -> FR {
+    return *reinterpret_cast<const FR*>(img + r * 128 + 16 * ((4 * ks + g) ^ ((r >> 1) & 7)));
+  };
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();     // neighbour table + epilogue vectors visible
+  asm volatile("" ::: "memory");
+  if (nsteps > 0) issue(0);
+  for (int step = 0; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of `step`
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // everyone's copies landed; everyone is done with step - 1
+    asm volatile("" ::: "memory");
+    if (step + 1 < nsteps) issue(step + 1);
+    const char* bx = stg + (step & 1) * STG;
+    const char* bw = bx + GC_BM * 128;
+    // group n = (K half-step ks = n / (MI/4), point quarter h = n % (MI/4)): 4 x NJ matrix-core steps
+    FR xf[2][4], wf[2][NJ];
+    auto load_group = [&](int n, FR (&x4)[4], FR (&w4)[NJ]) {
+      const int ks = n / (MI / 4), h = n % (MI / 4);
+      if (h == 0) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) w4[j] = frag(bw, (NJ * wc + j) * 16 + li, ks);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) x4[m] = frag(bx, (MI * wr + 4 * h + m) * 16 + li, ks);
+    };
+    load_group(0, xf[0], wf[0]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 + NJ, 0);
+    static_for<0, NGRP>([&](auto nc) {
+      constexpr int n = decltype(nc)::value;
+      constexpr int ks = n / (MI / 4), h = n % (MI / 4);
+      if constexpr (n + 1 < NGRP) load_group(n + 1, xf[(n + 1) & 1], wf[((n + 1) / (MI / 4)) & 1]);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[4 * h + m][j] = F::mma(wf[ks & 1][j], xf[n & 1][m], acc[4 * h + m][j]);
+      // the group's first matrix-core step (behind the compiler's wait for the group's fragments) goes ahead of the
+      // next group's reads, the rest of the group's steps run under them
+      constexpr int MPG = 4 * NJ * (F::E == 8 ? 1 : 4);   // matrix-core instructions per group (fp32: 4 per fragment pair)
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if constexpr (n + 1 < NGRP) __builtin_amdgcn_sched_group_barrier(0x100, ((n + 1) % (MI / 4) == 0) ? 4 + NJ : 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, MPG - 1, 0);
+    });
+  }
+  __syncthreads();   // operand images are dead: the output tile takes their place
+
+  // ---- epilogue: lane owns point (16 (MI wr + m) + li), channels n0 + 16 (NJ wc + j) + 4g .. +3
+  constexpr int OS = BN + 16 / (int)sizeof(T);
+  T* sOut = reinterpret_cast<T*>(gc_smem);
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const EpiVec ev = load_epi(sEpi, BN, (NJ * wc + j) * 16 + 4 * g);
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+      stage_values<T>(a, sOut, OS, (MI * wr + m) * 16 + li, (NJ * wc + j) * 16 + 4 * g, ev, acc[m][j]);
+  }
+  __syncthreads();
+  store_tile<T, 8>(a, sOut, OS, GC_BM, BN, row0, n0, tid, GC_THREADS);
+}
+
+// the 256-point tile is one workgroup per CU: it pays when its grid fills most of a round of 256 CUs
+static bool use_conv_tile(int64_t m, int cin, int cout, int kvol, int dtype, int64_t x_bytes, int* bn_out) {
+  const char* env = getenv("PTV3_CONV_TILE");   // 0 off, 1 policy (default), 2 force; read per call so tests can switch
+  const int mode = env ? atoi(env) : 1;
+  const int bk = dtype == PTV3_F32 ? 32 : 64, gran = dtype == PTV3_F32 ? 4 : 8;
+  if (mode == 0 || x_bytes <= 0 || kvol > GB_MAX_KVOL || kvol < 2 || cin % bk != 0 || cout % gran != 0 || cout < 128)
+    return false;
+  const int bn = (dtype == PTV3_BF16 && cout >= 256) ? 256 : 128;
+  *bn_out = bn;
+  if (mode == 2) return true;
+  const int64_t tiles = cdiv(m, GC_BM) * cdiv(cout, bn);
+  const int64_t rounds = cdiv(tiles, 256);
+  return tiles >= 160 && 4 * tiles >= 3 * rounds * 256 && (int64_t)kvol * cin >= 1024;
 }
 
 // the large tile pays once its grid fills the chip; below that the 64-point tile (+ split-K) has more workgroups
@@ -747,8 +959,16 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   PTV3_REQUIRE(out != nullptr || splits > 1, "gemm: out == NULL needs a split-K shape and its workspace");
   int cin_shift = -1;
   if ((cin & (cin - 1)) == 0) { cin_shift = 0; while ((1 << cin_shift) < cin) ++cin_shift; }
+  // gathered rows through a buffer descriptor (missing neighbours cost no memory access): x is the (m, cin) feature
+  // matrix of the m active sites the neighbour table was built for, and both operands must be addressable with 32-bit
+  // byte offsets.  PTV3_GEMM_BUF=0 keeps the pointer form (tools/bench_gemm_big.py compares them).
+  const int esz0 = dtype == PTV3_F32 ? 4 : 2;
+  const char* buf_env = getenv("PTV3_GEMM_BUF");
+  const bool buf_on = !(buf_env && atoi(buf_env) == 0);
+  const int64_t xb = m * cin * esz0, wb = (int64_t)cout * kvol * cin * esz0, lim = ((int64_t)1 << 31) - 4096;
+  const int64_t x_bytes = (nbr && buf_on && xb < lim && wb < lim) ? xb : 0;
   GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
-             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps};
+             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps, x_bytes};
   hipStream_t s = (hipStream_t)stream;
   int nt = choose_nt(cout);
   if (nbr && nt != 2) nt = 4;
@@ -758,6 +978,27 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
                               ((double)m * cin * (nbr ? 1 : kvol) + (double)cout * kvol * cin +
                                (double)m * cout * (1 + (res != nullptr) + (out2 != nullptr))) * esz,
                               nbr, m * kvol, 2.0 * cin * cout);
+  int ct_bn = 0;
+  const bool ctile = splits <= 1 && out != nullptr && nbr != nullptr && use_conv_tile(m, cin, cout, kvol, dtype, x_bytes, &ct_bn);
+  if (ctile) {
+    prof_kernel(prof, PK_CONV_TILE);
+    const size_t lds = (size_t)2 * (GC_BM + ct_bn) * 128 + (size_t)GC_BM * GB_MAX_KVOL * 4 + (size_t)3 * ct_bn * sizeof(float);
+    const size_t lds_out = (size_t)GC_BM * (ct_bn * esz + 16);
+    PTV3_REQUIRE(lds_out <= (size_t)2 * (GC_BM + ct_bn) * 128 + (size_t)GC_BM * GB_MAX_KVOL * 4, "conv tile: output tile exceeds the operand images");
+    dim3 cgrid((unsigned)(cdiv(m, GC_BM) * cdiv(cout, ct_bn)));
+#define GC_LAUNCH(T, BN_)                                                                                        \
+    do {                                                                                                         \
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_tile_kernel<T, BN_>), 160 * 1024);                  \
+      hipLaunchKernelGGL((conv_tile_kernel<T, BN_>), cgrid, dim3(GC_THREADS), lds, s, a);                        \
+    } while (0)
+    if (dtype == PTV3_F32) GC_LAUNCH(float, 128);
+    else if (ct_bn == 256) GC_LAUNCH(__bf16, 256);
+    else GC_LAUNCH(__bf16, 128);
+#undef GC_LAUNCH
+    prof_end(prof, s);
+    PTV3_LAUNCH_CHECK();
+    return PTV3_OK;
+  }
   prof_kernel(prof, big ? (nbr ? PK_GEMM_BIG_CONV : PK_GEMM_BIG_DENSE)
                         : nt == 2 ? (nbr ? PK_GEMM32_CONV : PK_GEMM32_DENSE) : (nbr ? PK_GEMM64_CONV : PK_GEMM64_DENSE));
   if (big) {
@@ -766,20 +1007,16 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
     static_assert(2 * (GB_BM + 128) * 128 + GB_BM * GB_MAX_KVOL * 4 + GB_MAX_STEPS + 32 + 3 * 128 * 4 <= 80 * 1024,
                   "gemm_big_kernel: two workgroups per CU need <= 80 KB of LDS each");
     dim3 bgrid((unsigned)(cdiv(m, GB_BM) * cdiv(cout, big_bn)));
-#define GB_LAUNCH(T, WM_, WN_, BN_, G_)                                                                          \
+#define GB_LAUNCH(T, WM_, WN_, BN_, G_, B_)                                                                      \
     do {                                                                                                         \
-      static bool attr_set = false;                                                                              \
-      if (!attr_set) {                                                                                           \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_big_kernel<T, WM_, WN_, BN_, G_>),         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                        \
-        attr_set = true;                                                                                         \
-      }                                                                                                          \
-      hipLaunchKernelGGL((gemm_big_kernel<T, WM_, WN_, BN_, G_>), bgrid, dim3(GB_THREADS), lds, s, a);           \
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_big_kernel<T, WM_, WN_, BN_, G_, B_>), 96 * 1024);  \
+      hipLaunchKernelGGL((gemm_big_kernel<T, WM_, WN_, BN_, G_, B_>), bgrid, dim3(GB_THREADS), lds, s, a);       \
     } while (0)
 #define GB_PICK(T)                                                                                               \
     do {                                                                                                         \
-      if (nbr) { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, true); else GB_LAUNCH(T, 4, 1, 64, true); }          \
-      else { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, false); else GB_LAUNCH(T, 4, 1, 64, false); }            \
+      if (nbr && x_bytes) { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, true, true); else GB_LAUNCH(T, 4, 1, 64, true, true); } \
+      else if (nbr) { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, true, false); else GB_LAUNCH(T, 4, 1, 64, true, false); }     \
+      else { if (big_bn == 128) GB_LAUNCH(T, 2, 2, 128, false, false); else GB_LAUNCH(T, 4, 1, 64, false, false); }            \
     } while (0)
     if (dtype == PTV3_F32) GB_PICK(float); else GB_PICK(__bf16);
 #undef GB_PICK

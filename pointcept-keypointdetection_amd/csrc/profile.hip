@@ -11,7 +11,8 @@ static const char* const g_kernel_names[PK_KERNELS] = {
     "gemm_kernel<64ch> dense", "gemm_kernel<64ch> gather (sparse conv)", "gemm_kernel<32ch> dense",
     "gemm_kernel<32ch> gather (sparse conv)", "gemm_big_kernel dense", "gemm_big_kernel gather (sparse conv)",
     "block_head_kernel", "block_tail_kernel", "block_head_coop_kernel", "block_tail_coop_kernel", "mlp2_kernel",
-    "window_attn_full_kernel", "window_attn_kernel", "block_head_wide_kernel", "block_tail_wide_kernel"};
+    "window_attn_full_kernel", "window_attn_kernel", "block_head_wide_kernel", "block_tail_wide_kernel",
+    "conv_tile_kernel (sparse conv)"};
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;

@@ -79,3 +79,52 @@ def test_sparse_conv_big_tile(dev, dtype, n, cin, cout):
     assert (b0.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
     ref2 = ref + res.float().cpu()[ridx.cpu().long()]
     assert (b1.float().cpu() - ref2).abs().max().item() < tol * max(1.0, ref2.abs().max().item())
+
+
+def _tiles(fn):
+    """the same call through the 64-point tile and through the 256-point LDS-DMA tile (conv_tile_kernel)"""
+    out = {}
+    for name, env in (("small", {"PTV3_GEMM_BIG": "0", "PTV3_CONV_TILE": "0"}), ("tile", {"PTV3_CONV_TILE": "2"})):
+        os.environ.update(env)
+        try:
+            out[name] = fn()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    return out["small"], out["tile"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,cin,cout", [(3000, 128, 128), (700, 256, 256), (1537, 64, 384), (300, 128, 136), (257, 512, 512)])
+def test_sparse_conv_256_point_tile(dev, dtype, n, cin, cout):
+    """conv_tile_kernel: operands by LDS-DMA through buffer descriptors - missing neighbours, rows past m (n is not a
+    multiple of 256) and channel rows past cout (384 and 136 leave a partial channel tile) arrive in LDS as zeros.
+    Bitwise against the 64-point tile (same K order), every epilogue option on; then against the conv restatement."""
+    from ptv3_hip import ops
+    import ptv3_scenes as S
+    from oracle import ptv3 as O
+    sc = S.make_scene(n, 4, 24, seed=n)
+    idx = torch.cat([torch.zeros(n, 1, dtype=torch.int32), torch.from_numpy(sc["grid_coord"]).int()], 1).contiguous()
+    g = torch.Generator().manual_seed(n)
+    feat = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) / (27 * cin) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    nbr, _ = ops.subm_neighbors(idx.to(dev), 3)
+    assert 0.05 < (nbr >= 0).float().mean().item() < 0.9          # the scene has missing neighbours
+    order = torch.randperm(n, generator=g).int().to(dev)
+    scale, shift = torch.rand(cout, generator=g).to(dev) + 0.5, torch.randn(cout, generator=g).to(dev)
+    ridx = torch.randint(0, 50, (n,), generator=g).int().to(dev)
+    res = torch.randn(50, cout, generator=g).to(dev, dtype)
+    xd, wd = feat.to(dev, dtype), w.reshape(cout, -1).to(dev, dtype).contiguous()
+
+    def run():
+        return ops.gemm(xd, wd, bias=bias.to(dev), nbr=nbr, kvol=27, row_order=order, bn_scale=scale, bn_shift=shift,
+                        act=ops.ACT_RELU, res=res, res_index=ridx, dual=True)
+    (s0, s1), (t0, t1) = _tiles(run)
+    assert torch.equal(s0, t0) and torch.equal(s1, t1)
+    plain_s, plain_t = _tiles(lambda: ops.gemm(xd, wd, nbr=nbr, kvol=27))
+    assert torch.equal(plain_s, plain_t)
+    ref = O.subm_conv3d(xd.float().cpu(), idx, wd.float().cpu().reshape(w.shape), bias)
+    ref = torch.relu(ref * scale.cpu() + shift.cpu())
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -6
+    assert (t0.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
