@@ -28,6 +28,7 @@ struct GemmArgs {
   float* slab;  // split-K partial sums [splits][m][cout] fp32 (NULL: direct epilogue)
   int64_t m; int cin; int cout; int kvol; int act; int cin_shift; int steps_per_split;
   int64_t x_bytes;   // size of x in bytes when it is known to be < 2^31 (buffer-descriptor addressing), else 0
+  int ablate;        // tools only (PTV3_CONV_ABLATE): bit 0 no matrix-core work / fragment reads, 1 no operand copies, 2 no waits / barriers
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -452,13 +453,26 @@ __global__ void __launch_bounds__(GB_THREADS) gemm_big_kernel(GemmArgs a) {
     if (tid == 0) sTapMask = 0u;
     __syncthreads();
     unsigned mask = 0u;
-    for (int e = tid; e < GB_BM * a.kvol; e += GB_THREADS) {
-      const int pr = e / a.kvol, d = e - pr * a.kvol;
+    {
+      // two threads per point, 14 taps each, all loads of a thread in flight at once (not one dependent
+      // row_order -> nbr round trip per element of an element-strided loop)
+      const int pr = tid >> 1, d0 = (tid & 1) * 14;
       const int64_t r = row0 + pr;
-      int32_t v = -1;
-      if (r < a.m) v = a.nbr[(a.row_order ? (int64_t)a.row_order[r] : r) * a.kvol + d];
-      sNbr[e] = v;
-      if (v >= 0) mask |= 1u << d;
+      const bool in = r < a.m;
+      const int64_t orow = in ? (a.row_order ? (int64_t)a.row_order[r] : r) : 0;
+      int32_t v[14];
+#pragma unroll
+      for (int u = 0; u < 14; ++u) {
+        const int d = d0 + u;
+        v[u] = a.nbr[orow * a.kvol + (d < a.kvol ? d : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 14; ++u)
+        if (d0 + u < a.kvol) {
+          const int32_t nb = in ? v[u] : -1;
+          sNbr[pr * a.kvol + d0 + u] = nb;
+          if (nb >= 0) mask |= 1u << (d0 + u);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, 64);
@@ -682,21 +696,32 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 
 #define PTV3_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <typename T, int BN>
+template <int N> __device__ __forceinline__ void gc_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// KB: bytes of K per row and stage (128 | 64); NSTG: stages in the LDS ring.  The copies of stage s + NSTG - 1 are
+// issued right after the barrier of stage s, so NSTG - 2 younger stages stay in flight across every barrier (a
+// counted s_waitcnt vmcnt in front of it).  Two stages of 128 bytes leave ONE stage in flight, issued when its
+// predecessor starts computing: the copies then have one stage's matrix-core time (~0.8 us) to come back from L2 and
+// the kernel waits for them (measured 1.77 us per K-step against 0.85 us of matrix-core work); four stages of 64
+// bytes hold the same LDS and keep two to three stages in flight.
+template <typename T, int BN, int KB, int NSTG>
 __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
-  constexpr int E = F::E;
-  constexpr int BK = 2 * F::KC;
+  constexpr int KS = KB / 64;                    // matrix-core K chunks per stage (16-byte fragments x 4 lane groups)
+  constexpr int BK = KS * F::KC;                 // K elements per stage
   constexpr int WN = BN / 64, WM = 8 / WN;       // waves across channels / points
   constexpr int MI = GC_BM / (16 * WM), NJ = 4;  // accumulator fragments per wave: MI x NJ (8 x 4 | 4 x 4)
-  constexpr int STG = (GC_BM + BN) * 128;        // bytes per stage
-  constexpr int XQ = GC_BM / 64, WQ = BN / 64;   // copies per wave and step
-  constexpr int NGRP = 2 * (MI / 4);             // fragment groups per K-step
+  constexpr int STG = (GC_BM + BN) * KB;         // bytes per stage
+  constexpr int RPI = 1024 / KB;                 // rows per copy instruction (8 | 16), KB / 16 lanes per row
+  constexpr int XQ = GC_BM / RPI / 8, WQ = BN / RPI / 8;   // copies per wave and stage
+  constexpr int DPS = XQ + WQ;
+  constexpr int NGRP = KS * (MI / 4);            // fragment groups per stage
+  constexpr int AH = NSTG - 1;                   // stages issued ahead
   extern __shared__ __attribute__((aligned(16))) char gc_smem[];
-  char* stg = gc_smem;                                                   // [2][STG]
-  int32_t* sNbr = reinterpret_cast<int32_t*>(gc_smem + 2 * STG);       // [256][kvol <= 27]
-  float* sEpi = reinterpret_cast<float*>(sNbr + GC_BM * GB_MAX_KVOL);  // [3][BN]
+  char* stg = gc_smem;                                                    // [NSTG][STG]
+  int32_t* sNbr = reinterpret_cast<int32_t*>(gc_smem + NSTG * STG);     // [256][kvol <= 27]
+  float* sEpi = reinterpret_cast<float*>(sNbr + GC_BM * GB_MAX_KVOL);   // [3][BN]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -709,10 +734,22 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
   const int ktot = a.kvol * a.cin;
   const int nsteps = ktot / BK;
 
-  for (int e = tid; e < GC_BM * a.kvol; e += GC_THREADS) {
-    const int pr = e / a.kvol, d = e - pr * a.kvol;
+  {
+    // neighbour rows of the tile's 256 points -> LDS: two threads per point, 14 taps each, every load of a thread in
+    // flight at once (an element-strided loop makes 14 dependent row_order -> nbr round trips: 20 us of a 190 us launch)
+    const int pr = tid >> 1, d0 = (tid & 1) * 14;
     const int64_t r = row0 + pr;
-    sNbr[e] = r < a.m ? a.nbr[(a.row_order ? (int64_t)a.row_order[r] : r) * a.kvol + d] : -1;
+    const bool in = r < a.m;
+    const int64_t orow = in ? (a.row_order ? (int64_t)a.row_order[r] : r) : 0;
+    int32_t v[14];
+#pragma unroll
+    for (int u = 0; u < 14; ++u) {
+      const int d = d0 + u;
+      v[u] = a.nbr[orow * a.kvol + (d < a.kvol ? d : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 14; ++u)
+      if (d0 + u < a.kvol) sNbr[pr * a.kvol + d0 + u] = in ? v[u] : -1;
   }
   park_epi(a, sEpi, BN, n0, tid, GC_THREADS);
 
@@ -720,29 +757,36 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(a.w), 0, (int)((int64_t)a.cout * ktot * (int)sizeof(T)), 0x00020000);
-  // copy q = wave + 8 i covers rows 8q .. 8q+7: lane -> (row 8q + lane / 8, LDS chunk lane % 8)
-  const int rr = lane >> 3, cch = lane & 7;
+  // LDS image of an operand: KB-byte rows; 16-byte chunk c of row r sits at chunk c ^ swz(r) (conflict-free
+  // ds_read_b128 of 16 consecutive rows).  Copy q = wave + 8 i covers rows RPI q .. RPI q + RPI - 1: lane ->
+  // (row RPI q + lane / (KB/16), LDS chunk lane % (KB/16)), fetching SOURCE chunk c ^ swz(row).
+  // (64-byte rows: a ds_read_b128 is served in four groups of 16 lanes that mix two lane quarters g - per row residue
+  // mod 4 the group holds row quarters (0, 1, 2, 3) with g = (a, b, b, a) - and chunk g ^ [0, 3, 2, 1][row quarter]
+  // gives its 16 lanes 16 different 16-byte slots of the 256-byte bank row)
+  auto swz = [](int r) { return KB == 128 ? ((r >> 1) & 7) : ((0 - (r >> 2)) & 3); };
+  constexpr int LPR = KB / 16;
+  const int rr = lane / LPR, cch = lane % LPR;
   int xnb[XQ];          // LDS index of the lane's row in the neighbour table (x kvol)
-  unsigned xcol[XQ];    // byte offset of the source chunk inside the step's 128 bytes
+  unsigned xcol[XQ];    // byte offset of the source chunk inside the stage's KB bytes
   unsigned woff[WQ];    // byte offset of (channel row, source chunk) in w, or out of range
 #pragma unroll
   for (int i = 0; i < XQ; ++i) {
-    const int r = 8 * (wave + 8 * i) + rr;
+    const int r = RPI * (wave + 8 * i) + rr;
     xnb[i] = r * a.kvol;
-    xcol[i] = (unsigned)((cch ^ ((r >> 1) & 7)) * 16);
+    xcol[i] = (unsigned)((cch ^ swz(r)) * 16);
   }
 #pragma unroll
   for (int i = 0; i < WQ; ++i) {
-    const int r = 8 * (wave + 8 * i) + rr;
+    const int r = RPI * (wave + 8 * i) + rr;
     const int o = n0 + r;
-    woff[i] = o < a.cout ? (unsigned)(((int64_t)o * ktot) * (int)sizeof(T)) + (unsigned)((cch ^ ((r >> 1) & 7)) * 16) : 0xFFFFFFF0u;
+    woff[i] = o < a.cout ? (unsigned)(((int64_t)o * ktot) * (int)sizeof(T)) + (unsigned)((cch ^ swz(r)) * 16) : 0xFFFFFFF0u;
   }
   const unsigned row_bytes = (unsigned)(a.cin * (int)sizeof(T));
   auto issue = [&](int step) {
-    char* buf = stg + (step & 1) * STG;
+    char* buf = stg + (step % NSTG) * STG;
     const int k0 = step * BK;
     const int d = a.cin_shift >= 0 ? (k0 >> a.cin_shift) : (k0 / a.cin);
-    const unsigned kb = (unsigned)((k0 - d * a.cin) * (int)sizeof(T));   // byte offset of the step's channels in a row of x
+    const unsigned kb = (unsigned)((k0 - d * a.cin) * (int)sizeof(T));   // byte offset of the stage's channels in a row of x
 #pragma unroll
     for (int i = 0; i < XQ; ++i) {
       const int src = sNbr[xnb[i] + d];
@@ -753,7 +797,7 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
       const unsigned off = woff[i] == 0xFFFFFFF0u ? woff[i] : woff[i] + kw;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, PTV3_LDS_PTR(buf + GC_BM * 128 + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, PTV3_LDS_PTR(buf + GC_BM * KB + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
     }
   };
 
@@ -765,21 +809,30 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
 
   // fragment of row r, K chunk (ks, g) of an operand image
   auto frag = [&](const char* img, int r, int ks) -> FR {
-    return *reinterpret_cast<const FR*>(img + r * 128 + 16 * ((4 * ks + g) ^ ((r >> 1) & 7)));
+    return *reinterpret_cast<const FR*>(img + r * KB + 16 * ((4 * ks + g) ^ swz(r)));
   };
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();     // neighbour table + epilogue vectors visible
   asm volatile("" ::: "memory");
-  if (nsteps > 0) issue(0);
+#pragma unroll
+  for (int i = 0; i < AH; ++i)
+    if (i < nsteps) issue(i);
   for (int step = 0; step < nsteps; ++step) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's copies of `step`
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                         // everyone's copies landed; everyone is done with step - 1
-    asm volatile("" ::: "memory");
-    if (step + 1 < nsteps) issue(step + 1);
-    const char* bx = stg + (step & 1) * STG;
-    const char* bw = bx + GC_BM * 128;
-    // group n = (K half-step ks = n / (MI/4), point quarter h = n % (MI/4)): 4 x NJ matrix-core steps
+    // this wave's copies of `step`: all but the copies of the younger stages that exist
+    const int rem = nsteps - 1 - step;
+    if (!(a.ablate & 4)) {
+      if (rem >= AH - 1) gc_wait_vm<(AH - 1) * DPS>();
+      else if (AH >= 3 && rem == 1) gc_wait_vm<DPS>();
+      else gc_wait_vm<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // everyone's copies landed; everyone is done with step - 1
+      asm volatile("" ::: "memory");
+    }
+    if (step + AH < nsteps && !(a.ablate & 2)) issue(step + AH);
+    if (a.ablate & 1) continue;
+    const char* bx = stg + (step % NSTG) * STG;
+    const char* bw = bx + GC_BM * KB;
+    // group n = (K chunk ks = n / (MI/4), point quarter h = n % (MI/4)): 4 x NJ matrix-core steps
     FR xf[2][4], wf[2][NJ];
     auto load_group = [&](int n, FR (&x4)[4], FR (&w4)[NJ]) {
       const int ks = n / (MI / 4), h = n % (MI / 4);
@@ -968,7 +1021,8 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   const int64_t xb = m * cin * esz0, wb = (int64_t)cout * kvol * cin * esz0, lim = ((int64_t)1 << 31) - 4096;
   const int64_t x_bytes = (nbr && buf_on && xb < lim && wb < lim) ? xb : 0;
   GemmArgs a{x, w, out, out2, res, nbr, row_order, res_index, bias, bn_scale, bn_shift,
-             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps, x_bytes};
+             splits > 1 ? (float*)workspace : nullptr, m, cin, cout, kvol, act, cin_shift, sps, x_bytes, 0};
+  if (const char* e = getenv("PTV3_CONV_ABLATE")) a.ablate = atoi(e);
   hipStream_t s = (hipStream_t)stream;
   int nt = choose_nt(cout);
   if (nbr && nt != 2) nt = 4;
@@ -982,18 +1036,24 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
   const bool ctile = splits <= 1 && out != nullptr && nbr != nullptr && use_conv_tile(m, cin, cout, kvol, dtype, x_bytes, &ct_bn);
   if (ctile) {
     prof_kernel(prof, PK_CONV_TILE);
-    const size_t lds = (size_t)2 * (GC_BM + ct_bn) * 128 + (size_t)GC_BM * GB_MAX_KVOL * 4 + (size_t)3 * ct_bn * sizeof(float);
+    // both ring shapes hold (256 + bn) x 256 bytes of operands: 4 stages x 64 bytes of K (default) or 2 x 128
+    const char* st_env = getenv("PTV3_CONV_STAGES");
+    const bool four = !(st_env && atoi(st_env) == 2);
+    const size_t lds_ops = (size_t)(GC_BM + ct_bn) * 256 + (size_t)GC_BM * GB_MAX_KVOL * 4;
+    const size_t lds = lds_ops + (size_t)3 * ct_bn * sizeof(float);
     const size_t lds_out = (size_t)GC_BM * (ct_bn * esz + 16);
-    PTV3_REQUIRE(lds_out <= (size_t)2 * (GC_BM + ct_bn) * 128 + (size_t)GC_BM * GB_MAX_KVOL * 4, "conv tile: output tile exceeds the operand images");
+    PTV3_REQUIRE(lds_out <= lds_ops, "conv tile: output tile exceeds the operand images");
     dim3 cgrid((unsigned)(cdiv(m, GC_BM) * cdiv(cout, ct_bn)));
-#define GC_LAUNCH(T, BN_)                                                                                        \
+#define GC_LAUNCH(T, BN_, KB_, NS_)                                                                              \
     do {                                                                                                         \
-      ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_tile_kernel<T, BN_>), 160 * 1024);                  \
-      hipLaunchKernelGGL((conv_tile_kernel<T, BN_>), cgrid, dim3(GC_THREADS), lds, s, a);                        \
+      ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_tile_kernel<T, BN_, KB_, NS_>), 160 * 1024);        \
+      hipLaunchKernelGGL((conv_tile_kernel<T, BN_, KB_, NS_>), cgrid, dim3(GC_THREADS), lds, s, a);              \
     } while (0)
-    if (dtype == PTV3_F32) GC_LAUNCH(float, 128);
-    else if (ct_bn == 256) GC_LAUNCH(__bf16, 256);
-    else GC_LAUNCH(__bf16, 128);
+#define GC_PICK(T, BN_) do { if (four) GC_LAUNCH(T, BN_, 64, 4); else GC_LAUNCH(T, BN_, 128, 2); } while (0)
+    if (dtype == PTV3_F32) GC_PICK(float, 128);
+    else if (ct_bn == 256) GC_PICK(__bf16, 256);
+    else GC_PICK(__bf16, 128);
+#undef GC_PICK
 #undef GC_LAUNCH
     prof_end(prof, s);
     PTV3_LAUNCH_CHECK();
