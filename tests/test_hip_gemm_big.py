@@ -20,10 +20,13 @@ def _both(fn):
     out = {}
     for mode in ("0", "2"):
         os.environ["PTV3_GEMM_BIG"] = mode
+        os.environ["PTV3_GEMM_SPLITK"] = "0"     # one pass over K in both: the same summation order
+        os.environ["PTV3_CONV_TILE"] = "0"
         try:
             out[mode] = fn()
         finally:
-            os.environ.pop("PTV3_GEMM_BIG", None)
+            for k in ("PTV3_GEMM_BIG", "PTV3_GEMM_SPLITK", "PTV3_CONV_TILE"):
+                os.environ.pop(k, None)
     return out["0"], out["2"]
 
 
@@ -84,7 +87,7 @@ def test_sparse_conv_big_tile(dev, dtype, n, cin, cout):
 def _tiles(fn):
     """the same call through the 64-point tile and through the 256-point LDS-DMA tile (conv_tile_kernel)"""
     out = {}
-    for name, env in (("small", {"PTV3_GEMM_BIG": "0", "PTV3_CONV_TILE": "0"}), ("tile", {"PTV3_CONV_TILE": "2"})):
+    for name, env in (("small", {"PTV3_GEMM_BIG": "0", "PTV3_CONV_TILE": "0", "PTV3_GEMM_SPLITK": "0"}), ("tile", {"PTV3_CONV_TILE": "2"})):
         os.environ.update(env)
         try:
             out[name] = fn()
