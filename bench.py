@@ -13,13 +13,18 @@ process per GPU, `init_process_group("nccl")` over tcp://127.0.0.1:<free port>, 
 reference's pointcept/engines/launch.py:36-113 - and returns their exit code.
 
 Prints ONE JSON line on rank 0 with
-  value / ms_per_step     K forwards in the timed region (two in flight, see config.forwards_in_flight)
-  latency_ms_median       SURVEY 8(d)'s metric: median of >= 20 single forwards, each bracketed by synchronize
-  fp32                    the same two figures in fp32 (exact-fp32 MFMA), the arithmetic of the 1e-4 parity bar
+  value / ms_per_step     SURVEY 8(d)'s figure: K single forwards, each followed by torch.cuda.synchronize(), timed as
+                          one region between barrier + synchronize (one forward in flight at any time)
+  latency_ms_median       the median of those K single forwards (and latency_mpoints_per_s)
+  throughput_2_in_flight  the same K forwards WITHOUT the per-step synchronize, two in flight (the executor's
+                          throughput mode); --no-overlap: one in flight, back to back
+  fp32                    the same figures in fp32 (exact-fp32 MFMA), the arithmetic of the 1e-4 parity bar
   parity                  fp32 AND bf16 outputs of the HIP path vs the oracle on the cpu_baseline scene
-  roofline                dominant kernel family, HIP-event timed on the launch stream
-  cpu_baseline            the oracle on the host cores (N = 1 only, bounded sample)
-  other_workloads         BASELINE configs[2]: PTv3 semseg (enable_flash=True) on a 120k-point LiDAR-like scan
+  roofline                dominant KERNEL, HIP-event timed on the launch stream in this run (traffic: null - the PMC
+                          passes are separate runs; their committed summaries are quoted under pmc_replayed)
+  cpu_baseline            the oracle on the host cores (N = 1 only, bounded sample: median of 5 forwards)
+  other_workloads         BASELINE configs[2] (PTv3 semseg on a 120k-point LiDAR-like scan, with its own roofline),
+                          configs[4] (Swin3D-S), configs[3]'s per-GPU share (one training step, with its roofline)
 """
 import argparse
 import json
@@ -83,45 +88,39 @@ def _pmc_label(kernel, dtype):
     return kernel.replace("gemm_big_kernel ", f"gemm_big_kernel<{dt},128ch> ")
 
 
-def pmc_traffic(args, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (tools/measure_round.sh ->
-    profiles/<round>/pmc_traffic.json), if they were taken on this workload."""
+def pmc_replayed(tag, kernel):
+    """Counter summaries of the committed rocprofv3 --pmc passes over the SAME command (tools/measure_round.sh ->
+    profiles/<round>/pmc_traffic*.json, pmc_sq*.json; tag = "default" | "lidar").  They were NOT measured in this run:
+    the block says where it was replayed from and sits outside `roofline`."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json")))
-    if not files:
-        return None, None
-    data = json.load(open(files[-1]))
-    w = data.get("workload", {})
-    if (w.get("points"), w.get("scenes"), w.get("dtype"), w.get("kind")) != (args.points, args.scenes, args.dtype, args.kind):
-        return None, None
-    want = _pmc_label(kernel, args.dtype)
-    hits = [v for k, v in data["kernels"].items()
-            if k.replace(",pd4", "") == want or (want.startswith("window_attn_full_kernel") and k.startswith(want))]
-    if not hits:
-        return None, None
-    step = sum(h["hbm_bytes_per_step"] for h in hits)
-    launches = sum(h["launches_per_step"] for h in hits)
-    detail = {"source": os.path.relpath(files[-1], ROOT), "kernel": want, "hbm_mb_per_step": round(step / 1e6, 1),
-              "launches_per_step": launches}
-    raw = [h.get("fetch_bytes_per_step_raw") for h in hits]
-    if all(r is not None for r in raw):   # gathered reads: FETCH_SIZE x1 .. x2 (see tools/pmc_traffic.py)
-        detail["hbm_mb_per_step_low"] = round((step - sum(raw)) / 1e6, 1)
-    return step / max(launches, 1e-9), detail
-
-
-def pmc_sq():
-    """Matrix-core utilisation and stall shares of the two main kernels from the committed SQ counter pass
-    (tools/measure_round.sh -> profiles/<round>/pmc_sq.json; default workload only)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_sq.json")))
-    if not files:
-        return None
-    data = json.load(open(files[-1])).get("kernels", {})
-    keep = ("mfma_util", "share_issuing", "share_issue_stall", "share_parked")
-    out = {k: {f: v[f] for f in keep if f in v} for k, v in data.items()
-           if k.startswith(("window_attn_full_kernel", "gemm_kernel<bf16,64ch", "gemm_big_kernel", "block_"))}
-    return {"source": os.path.relpath(files[-1], ROOT),
-            "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)", **out} if out else None
+    suffix = "" if tag == "default" else "_" + tag
+    out = {}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_traffic{suffix}.json")))
+    if files and kernel:
+        data = json.load(open(files[-1]))
+        want = _pmc_label(kernel, "bf16")
+        hits = [v for k, v in data.get("kernels", {}).items()
+                if k.replace(",pd4", "") == want or (want.startswith("window_attn_full_kernel") and k.startswith(want))
+                or k.startswith(want.split(" (")[0])]
+        if hits:
+            step = sum(h["hbm_bytes_per_step"] for h in hits)
+            launches = sum(h["launches_per_step"] for h in hits)
+            out["traffic"] = {"replayed_from": os.path.relpath(files[-1], ROOT), "kernel": want,
+                              "hbm_mb_per_launch": round(step / max(launches, 1e-9) / 1e6, 3),
+                              "hbm_mb_per_step": round(step / 1e6, 1), "launches_per_step": launches}
+            raw = [h.get("fetch_bytes_per_step_raw") for h in hits]
+            if all(r is not None for r in raw):   # gathered reads: FETCH_SIZE x1 .. x2 (see tools/pmc_traffic.py)
+                out["traffic"]["hbm_mb_per_step_low"] = round((step - sum(raw)) / 1e6, 1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"pmc_sq{suffix}.json")))
+    if files:
+        data = json.load(open(files[-1])).get("kernels", {})
+        keep = ("mfma_util", "share_issuing", "share_issue_stall", "share_parked")
+        sq = {k: {f: v[f] for f in keep if f in v} for k, v in data.items()
+              if k.startswith(("window_attn_full_kernel", "gemm_kernel<bf16,64ch", "gemm_big_kernel", "block_", "conv_tile"))}
+        if sq:
+            out["sq"] = {"replayed_from": os.path.relpath(files[-1], ROOT),
+                         "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)", **sq}
+    return out or None
 
 
 def parse(argv=None):
@@ -177,15 +176,23 @@ def self_launch(args, argv):
     procs = [ctx.Process(target=_rank_entry, args=(r, args.gpus, port, argv)) for r in range(args.gpus)]
     for p in procs:
         p.start()
+    # poll: a rank that dies early (e.g. during init) leaves the others inside init_process_group or a collective until
+    # the communicator's timeout; on the first non-zero exit the remaining ranks are terminated
     code = 0
-    for p in procs:
-        p.join()
-        code = code or (p.exitcode or 0)
+    while any(p.is_alive() for p in procs) and not code:
+        for p in procs:
+            p.join(timeout=0.2)
+            if p.exitcode not in (None, 0):
+                code = p.exitcode
+                break
     if code:
         for p in procs:
             if p.is_alive():
                 p.terminate()
-    return code
+        for p in procs:
+            p.join(timeout=10)
+        return code
+    return max((p.exitcode or 0) for p in procs)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -236,6 +243,16 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("PTV3_BENCH_CPU_THREADS", "16"))))
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(sd, cfg, model, device, n_points):
     """Oracle (CPU restatement of the reference path) on the host cores + parity of the HIP path - in fp32 (the
     1e-4 bar) AND in bf16 (the arithmetic `value` is measured in) - on the same scene."""
@@ -245,11 +262,14 @@ def cpu_baseline(sd, cfg, model, device, n_points):
     torch.set_num_threads(cores)
     data = S.make_batch([n_points], in_channels=4, extent=None, seed=7)
     orc = O.OffsetKeypointOracle(cfg, sd)
-    torch.manual_seed(11)
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ref = orc.forward(data)
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(int(os.environ.get("PTV3_BENCH_CPU_REPS", "5"))):   # median of 5
+        torch.manual_seed(11)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            ref = orc.forward(data)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
     parity = {"tolerance_fp32": 1e-4, "sample_points": n_points,
               "reference": "oracle (torch-CPU fp32 restatement, pinned to the reference by tests/golden)",
               "logit_scale": round(ref["logits"].abs().max().item(), 4)}
@@ -265,8 +285,10 @@ def cpu_baseline(sd, cfg, model, device, n_points):
         parity[name] = {"offset_l2_max": d3.max().item(), "offset_l2_mean": d3.mean().item(),
                         "mask_prob_abs_max": dm.max().item(), "mask_prob_abs_mean": dm.mean().item()}
     return ({"value": round(n_points / dt / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "port",
-             "sample": f"oracle (torch-CPU fp32 restatement) forward of one {n_points}-point surface scene, "
-                       f"{dt:.1f} s wall, {cores} threads"}, parity)
+             "cpu_model": cpu_model(), "threads": cores,
+             "sample": f"oracle (torch-CPU fp32 restatement) forward of one {n_points}-point surface scene: median of "
+                       f"{len(times)} runs = {dt:.2f} s wall (min {min(times):.2f}, max {max(times):.2f}), {cores} threads"},
+            parity)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -290,29 +312,93 @@ def timed_steps(step, steps, warmup, world, device):
     return reduce_over_ranks(time.perf_counter() - t0, device, dist.ReduceOp.MAX)
 
 
-def latency_median(step, iters):
-    """median wall time of single forwards, torch.cuda.synchronize() on both sides of each."""
-    ts = []
+def synced_steps(step, steps, warmup, world, device):
+    """W untimed forwards, then K single forwards with torch.cuda.synchronize() after EACH, the K of them
+    timed as one region between barrier + synchronize; (elapsed MAX over ranks, median single-forward ms)."""
+    for _ in range(warmup):
+        step()
     torch.cuda.synchronize()
-    for _ in range(iters):
-        t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ts = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t1 = time.perf_counter()
         step()
         torch.cuda.synchronize()
-        ts.append((time.perf_counter() - t0) * 1e3)
-    return statistics.median(ts)
+        ts.append((time.perf_counter() - t1) * 1e3)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return reduce_over_ranks(time.perf_counter() - t0, device, dist.ReduceOp.MAX), statistics.median(ts)
 
 
 def forward_figures(model, batch, key, args, world, device, overlap):
-    """(elapsed of K steps in throughput mode, median single-forward latency in ms)"""
+    """elapsed of K synchronised single forwards, their median (ms), elapsed of K forwards in throughput mode, step fn"""
     def step():
         with torch.no_grad():
             return model(batch)[key]
+    model.backbone.overlap_calls = False
+    elapsed, lat = synced_steps(step, args.steps, args.warmup, world, device)
     model.backbone.overlap_calls = overlap
-    elapsed = timed_steps(step, args.steps, args.warmup, world, device)
+    thr = timed_steps(step, args.steps, args.warmup, world, device)
     model.backbone.overlap_calls = False
     step()
-    lat = latency_median(step, max(20, args.steps))
-    return elapsed, lat, step
+    torch.cuda.synchronize()
+    return elapsed, lat, thr, step
+
+
+def kernel_roofline(step, steps, dtype_name, rank=0):
+    """Per-KERNEL durations of `steps` more steps with HIP events on the launch stream around every bracketed launch
+    (ptv3_profile_enable; one forward in flight, so a bracket times its kernel alone), and the roofline entry of the
+    dominant kernel: its algorithmic bytes / flops per launch over its average launch duration - the quantity a
+    rocprofv3 --kernel-trace --stats summary of this command gives for the same kernel name.  Kept out of the timed
+    region: the ~340 event records per step are queue markers that cost ~1.5 ms per step."""
+    from ptv3_hip import ops
+    ops.profile_enable(True)
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    kern = ops.profile_collect_kernels()   # per KERNEL (one launch per bracket); before the family collect
+    fam = ops.profile_collect()
+    ops.profile_enable(False)
+    if not kern:
+        return None
+    dom = max(kern, key=lambda k: kern[k]["ms"])
+    d = kern[dom]
+    tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    # which roof binds it: algorithmic intensity against the machine balance of the dtype
+    intensity = d["flops"] / max(d["bytes"], 1.0)
+    hbm_bound = intensity * PEAK_HBM * 1e9 < PEAK[dtype_name] * 1e12
+
+    def per_kernel(v):
+        n = max(1, v["launches"])
+        return {"ms_per_step": round(v["ms"] / steps, 4), "launches_per_step": round(v["launches"] / steps, 1),
+                "avg_launch_us": round(v["ms"] * 1e3 / n, 2),
+                "algorithmic_mb_per_launch": round(v["bytes"] / n / 1e6, 4),
+                "algorithmic_gflop_per_launch": round(v["flops"] / n / 1e9, 4),
+                "gbps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
+                "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
+    fam = {k: v for k, v in fam.items() if v["launches"]}
+    return {"kernel": dom, "measured": f"HIP events on the launch stream around every launch of the kernel, {steps} extra "
+                                       "steps after the timed region, one step in flight",
+            "bound": "hbm" if hbm_bound else "mfma",
+            "achieved": round(gbs if hbm_bound else tf, 3),
+            "peak": PEAK_HBM if hbm_bound else PEAK[dtype_name],
+            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[dtype_name]), 5),
+            "traffic": None,
+            "intensity_flop_per_byte": round(intensity, 1),
+            "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
+            "launches_per_step": round(d["launches"] / steps, 1),
+            "algorithmic_gflop_per_step": round(d["flops"] / steps / 1e9, 3),
+            "algorithmic_mb_per_step": round(d["bytes"] / steps / 1e6, 3),
+            "families_ms_per_step": {k: round(v["ms"] / steps, 3) for k, v in fam.items()},
+            "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()},
+            "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()},
+            "kernels": {k: per_kernel(v) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
 
 
 def semseg_lidar_workload(device, args, world):
@@ -322,10 +408,8 @@ def semseg_lidar_workload(device, args, world):
     model.backbone.compute_dtype = torch.bfloat16
     model.backbone.inputs_resident = True
     batch = {k: v.to(device) for k, v in S.collate([make_scene(120000, "lidar", 1000)]).items()}
-    # throughput mode like the headline (two forwards in flight): 10.7 ms per step against 12.0 back to back.  (While every
-    # executor created its own streams this mode measured anywhere between 10.8 and 19.8 ms here - a second stream set
-    # shares hardware queues; with the per-device streams it is steady.)
-    elapsed, lat, step = forward_figures(model, batch, "seg_logits", args, world, device, True)
+    elapsed, lat, thr, step = forward_figures(model, batch, "seg_logits", args, world, device, True)
+    roof = kernel_roofline(step, args.steps, "bf16")
     with torch.no_grad():
         pts = model(batch, return_point=True)["point"]["_stage_points"]
     torch.cuda.synchronize()
@@ -333,7 +417,11 @@ def semseg_lidar_workload(device, args, world):
                         "1 x 120000-point LiDAR-like scan, 2048^3 grid (depth 11), bf16",
             "value": round(120000 * args.steps / elapsed / 1e6, 4), "unit": "Mpoints/s",
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "latency_ms_median": round(lat, 3),
-            "forwards_in_flight": 2, "stage_points": pts}
+            "latency_mpoints_per_s": round(120000 / lat / 1e3, 4),
+            "throughput_2_in_flight": {"value": round(120000 * args.steps / thr / 1e6, 4), "unit": "Mpoints/s",
+                                       "ms_per_step": round(thr / args.steps * 1e3, 3)},
+            "stage_points": pts, "roofline": roof,
+            "pmc_replayed": pmc_replayed("lidar", roof["kernel"] if roof else None)}
 
 
 def train_step_workload(device, args):
@@ -359,9 +447,11 @@ def train_step_workload(device, args):
 
     steps = 10
     elapsed = timed_steps(step, steps, 3, 1, device)
+    roof = kernel_roofline(step, steps, "bf16")
     return {"workload": "OffsetKeypointPTv3 (fork config, 46.2M params) train step: forward + backward + fused AdamW, "
                         "1 x 100000-point scene, bf16 activations, drop_path 0.3", "value": round(1e5 * steps / elapsed / 1e6, 4),
-            "unit": "Mpoints/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "final_loss": float(last["loss"].item())}
+            "unit": "Mpoints/s", "ms_per_step": round(elapsed / steps * 1e3, 3), "final_loss": float(last["loss"].item()),
+            "roofline": roof}
 
 
 def swin3d_workload(device, points=300000):
@@ -432,6 +522,7 @@ def train_bench(args, model, device, world, rank, local_rank):
     elapsed = timed_steps(step, args.steps, args.warmup, world, device)
     total_points = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
     probe = allreduce_probe(device, GRAD_BYTES) if world > 1 else None
+    roof = kernel_roofline(step, args.steps, args.dtype, rank) if not args.no_kernel_events else None
     if rank == 0:
         print(json.dumps({
             "metric": "Mpoints/sec PTv3 train step (fwd+bwd+AdamW) @100k pts/scene, 1024-pt window",
@@ -446,7 +537,7 @@ def train_bench(args, model, device, world, rank, local_rank):
                        "parallelism": f"dp{world} (DDP over RCCL, {GRAD_BYTES / 1e6:.1f} MB fp32 gradient all-reduce)"
                        if world > 1 else "dp1"},
             "rccl_ranks": world, "allreduce_probe": probe,
-            "roofline": None, "cpu_baseline": None, "final_loss": float(last["loss"].item())}), flush=True)
+            "roofline": roof, "cpu_baseline": None, "final_loss": float(last["loss"].item())}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -518,72 +609,25 @@ def run(args):
     # two forwards in flight (the small deep levels of step i run under the chip-filling level-0 kernels of step
     # i+1); every step is still one complete forward of the scene and all of them finish inside the timed region.
     # Then SURVEY 8(d)'s figure: the median of single, synchronize-bracketed forwards (one in flight).
-    elapsed, latency, step = forward_figures(model, batch, out_key, args, world, device, not args.no_overlap)
+    elapsed, latency, thr, step = forward_figures(model, batch, out_key, args, world, device, not args.no_overlap)
     total_points = reduce_over_ranks(n_points, device, dist.ReduceOp.SUM)
 
-    # ---- kernel durations: the SAME K steps again with HIP events on the launch stream around every
-    # matrix-core launch.  Kept out of the timed region above because the ~340 event records per step are
-    # queue markers that cost ~1.5 ms per step (measured: 5.0 ms vs 3.4 ms) - they would falsify `value`.
+    # ---- kernel durations: the SAME K steps again with HIP events on the launch stream around every matrix-core launch
     roofline = None
     if not args.no_kernel_events:
-        # one forward in flight here: with two overlapped forwards an event bracket would time the kernel while it
-        # shares the chip with the other forward's kernels; the roofline entry describes the kernel alone
         model.backbone.overlap_calls = False
-        ops.profile_enable(True)
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        kern = ops.profile_collect_kernels()   # per KERNEL (one launch per bracket); before the family collect
-        fam = ops.profile_collect()
-        ops.profile_enable(False)
-        # the dominant KERNEL (not family): its algorithmic bytes / flops per launch over its average launch duration -
-        # the quantity a rocprofv3 --kernel-trace --stats summary of this command gives for the same kernel name
-        dom = max(kern, key=lambda k: kern[k]["ms"])
-        d = kern[dom]
-        tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-        # which roof binds it: algorithmic intensity against the machine balance of the dtype
-        intensity = d["flops"] / max(d["bytes"], 1.0)
-        hbm_bound = intensity * PEAK_HBM * 1e9 < PEAK[args.dtype] * 1e12
-
-        def per_kernel(v):
-            n = max(1, v["launches"])
-            return {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
-                    "avg_launch_us": round(v["ms"] * 1e3 / n, 2),
-                    "algorithmic_mb_per_launch": round(v["bytes"] / n / 1e6, 4),
-                    "algorithmic_gflop_per_launch": round(v["flops"] / n / 1e9, 4),
-                    "gbps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1),
-                    "tflops": round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)}
-        roofline = {"kernel": dom, "measured": f"HIP events on the launch stream around every launch of the kernel, {args.steps} extra "
-                                "steps after the timed region, one forward in flight",
-                    "bound": "hbm" if hbm_bound else "mfma",
-                    "achieved": round(gbs if hbm_bound else tf, 3),
-                    "peak": PEAK_HBM if hbm_bound else PEAK[args.dtype],
-                    "unit": "GB/s" if hbm_bound else "TFLOP/s",
-                    "frac": round((gbs / PEAK_HBM) if hbm_bound else (tf / PEAK[args.dtype]), 5),
-                    "traffic": None, "traffic_detail": None,
-                    "intensity_flop_per_byte": round(intensity, 1),
-                    "avg_launch_us": round(d["ms"] * 1e3 / max(1, d["launches"]), 2),
-                    "launches_per_step": d["launches"] // args.steps,
-                    "algorithmic_gflop_per_step": round(d["flops"] / args.steps / 1e9, 3),
-                    "algorithmic_mb_per_step": round(d["bytes"] / args.steps / 1e6, 3),
-                    "families_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in fam.items()},
-                    "families_tflops": {k: round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2) for k, v in fam.items()},
-                    "families_gbps": {k: round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1) for k, v in fam.items()},
-                    "kernels": {k: per_kernel(v) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}}
-        if rank == 0:
-            roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(args, roofline["kernel"])
-            if (args.points, args.scenes, args.dtype, args.kind, args.model) == (100000, 1, "bf16", "surface", "offset"):
-                roofline["pmc_sq"] = pmc_sq()
+        roofline = kernel_roofline(step, args.steps, args.dtype, rank)
 
     # ---- the same workload in fp32 (the arithmetic of the 1e-4 parity bar), and BASELINE configs[2]
     fp32, extra = None, None
     default_run = world == 1 and not args.no_extra and args.model == "offset"
     if default_run and args.dtype == "bf16":
         model.backbone.compute_dtype = torch.float32
-        e32, l32, _ = forward_figures(model, batch, out_key, args, world, device, not args.no_overlap)
+        e32, l32, t32, _ = forward_figures(model, batch, out_key, args, world, device, not args.no_overlap)
         fp32 = {"value": round(n_points * args.steps / e32 / 1e6, 4), "unit": "Mpoints/s",
-                "ms_per_step": round(e32 / args.steps * 1e3, 3), "latency_ms_median": round(l32, 3)}
+                "ms_per_step": round(e32 / args.steps * 1e3, 3), "latency_ms_median": round(l32, 3),
+                "throughput_2_in_flight": {"value": round(n_points * args.steps / t32 / 1e6, 4),
+                                           "ms_per_step": round(t32 / args.steps * 1e3, 3)}}
         model.backbone.compute_dtype = dtype
     if default_run and rank == 0:
         del model, batch
@@ -608,12 +652,18 @@ def run(args):
                                    f"{args.scenes} x {args.points}-point synthetic {args.kind} scene(s) per GPU, "
                                    f"patch 1024, serialization + sparse conv + attention + head included",
                        "points_per_gpu": n_points, "parallelism": f"replicas x{world} (scene-sharded, no collective)",
-                       "forwards_in_flight": 1 if args.no_overlap else 2},
+                       "forwards_in_flight": 1,
+                       "timing": "K single forwards, torch.cuda.synchronize() after each (SURVEY 8d), one timed region"},
             "latency_ms_median": round(latency, 3),
             "latency_mpoints_per_s": round(n_points / latency / 1e3, 4),
+            "throughput_2_in_flight": {"value": round(total_points * args.steps / thr / 1e6, 4), "unit": "Mpoints/s",
+                                       "ms_per_step": round(thr / args.steps * 1e3, 3),
+                                       "forwards_in_flight": 1 if args.no_overlap else 2},
             "rccl_ranks": seen,
             "fp32": fp32,
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_workloads": extra,
+            "pmc_replayed": pmc_replayed("lidar" if args.kind == "lidar" else "default", roofline["kernel"] if roofline else None)
+            if (args.points, args.scenes, args.dtype) in ((100000, 1, "bf16"), (120000, 1, "bf16")) else None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

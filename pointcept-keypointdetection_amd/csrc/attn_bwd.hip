@@ -11,6 +11,7 @@
 // touch LDS).  The gather through win_order is fused into the loads; gradients are produced per padded slot
 // and folded back to points afterwards (a borrowed point sits in two slots: kept slot + one duplicate).
 #include "common.h"
+#include "profile.h"
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -384,13 +385,20 @@ __global__ void __launch_bounds__(256) unpad_add_kernel(const T* __restrict__ dp
 template <typename T, int ND>
 static void launch_attn_bwd(const AttnBwdArgs& a, hipStream_t s) {
   const unsigned blocks = (unsigned)a.nwin * a.heads * ((a.patch + 63) / 64);
-  if (a.table) {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND, true>), dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND, true>), dim3(blocks), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND, false>), dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND, false>), dim3(blocks), dim3(256), 0, s, a);
-  }
+  // recompute form: pass A = S, P, dP, dS and dQ (4 products of len^2 d per head), pass B = S, P, dP, dS, dK, dV (5):
+  // 2 len^2 c flops per product and window (uniform windows assumed for the count)
+  const double prod = 2.0 * (double)a.nwin * a.patch * (double)a.patch * a.c;
+  const double bytes = (double)a.nwin * a.patch * a.c * sizeof(T) * 5.0;
+  int prof = prof_begin(s, PROF_BACKWARD, 4.0 * prod, bytes, nullptr, 0, 0.0);
+  prof_kernel(prof, PK_ATTN_BWD_DQ);
+  if (a.table) hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<T, ND, false>), dim3(blocks), dim3(256), 0, s, a);
+  prof_end(prof, s);
+  prof = prof_begin(s, PROF_BACKWARD, 5.0 * prod, bytes, nullptr, 0, 0.0);
+  prof_kernel(prof, PK_ATTN_BWD_DKV);
+  if (a.table) hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND, true>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, ND, false>), dim3(blocks), dim3(256), 0, s, a);
+  prof_end(prof, s);
 }
 
 // dtable[j][h] = sum over the pass-A workgroups of head h (block id = (window * heads + h) * qblocks + qb) of their

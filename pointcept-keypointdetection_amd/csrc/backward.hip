@@ -4,6 +4,7 @@
 //   gather backward of SerializedPooling / SerializedUnpooling.
 // All reductions over points are deterministic: fixed row chunks -> fp32 slabs -> slab-ordered sum.
 #include "common.h"
+#include "profile.h"
 #include <stdlib.h>
 #include "../../include/ptv3_hip.h"
 
@@ -676,11 +677,19 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
     static_assert(lds >= 64 * 64 * sizeof(float) && lds <= 64 * 1024, "gemm_tn LDS");                     \
     hipLaunchKernelGGL((gemm_tn_kernel<T, RB, LS>), grid, dim3(256), lds, s, a);                          \
   } while (0)
+  // weight gradient dW = dY^T gather(X): 2 m cout kvol cin flops dense (active pairs counted on the device for a
+  // conv); reads dY once and X once (gathered), writes the fp32 gradient slabs
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_BACKWARD, 2.0 * m * cout * (double)kvol * cin,
+                              ((double)m * (cout + cin)) * esz + (double)ns * nw * 4.0, nbr, nbr ? m * kvol : 0,
+                              2.0 * cin * cout);
+  prof_kernel(prof, PK_GEMM_TN);
   if (dtype == PTV3_F32) {
     TN_LAUNCH(float, 64, 68);
   } else {
     if (rbsel == 128) TN_LAUNCH(__bf16, 128, 196); else TN_LAUNCH(__bf16, 64, 68);
   }
+  prof_end(prof, s);
 #undef TN_LAUNCH
   if (ns > 1) {
     if (dbias) slab_sum((const float*)workspace, (int)ns, nw + cout, dw, s, nw, dbias);

@@ -12,7 +12,7 @@ static const char* const g_kernel_names[PK_KERNELS] = {
     "gemm_kernel<32ch> gather (sparse conv)", "gemm_big_kernel dense", "gemm_big_kernel gather (sparse conv)",
     "block_head_kernel", "block_tail_kernel", "block_head_coop_kernel", "block_tail_coop_kernel", "mlp2_kernel",
     "window_attn_full_kernel", "window_attn_kernel", "block_head_wide_kernel", "block_tail_wide_kernel",
-    "conv_tile_kernel (sparse conv)"};
+    "conv_tile_kernel (sparse conv)", "gemm_tn_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel"};
 static bool g_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -40,7 +40,7 @@ static hipEvent_t get_event() {
 int prof_begin(hipStream_t s, int family, double flops, double bytes, const int32_t* nbr, int64_t nbr_count,
                double flops_per_valid) {
   if (!g_on) return -1;
-  static const int default_kernel[PROF_FAMILIES] = {PK_GEMM64_DENSE, PK_GEMM64_CONV, PK_ATTN_FULL};
+  static const int default_kernel[PROF_FAMILIES] = {PK_GEMM64_DENSE, PK_GEMM64_CONV, PK_ATTN_FULL, PK_GEMM_TN};
   ProfRec r{family, flops, bytes, flops_per_valid, get_event(), get_event(), -1, default_kernel[family]};
   if (nbr && g_slots && g_nslots < MAX_SLOTS) {
     r.slot = g_nslots++;

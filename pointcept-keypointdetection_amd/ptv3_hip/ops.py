@@ -894,7 +894,7 @@ def knn_query_cells(nsample, xyz, offset, new_xyz, new_offset, cell=None):
 # ---------------------------------------------------------------------------------------------
 # measurement
 # ---------------------------------------------------------------------------------------------
-FAMILIES = ("linear", "subm_conv", "window_attn")
+FAMILIES = ("linear", "subm_conv", "window_attn", "backward")
 
 
 def profile_enable(on=True):

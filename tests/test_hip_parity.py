@@ -160,17 +160,49 @@ def test_window_attention_launch_configs_bitwise(dev, dtype):
             os.environ.pop("PTV3_ATTN_QT", None)
 
 
-def test_window_attention_bf16(dev, golden_dir):
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+def test_window_attention_bf16(dev, golden_dir, case):
+    """bf16 kernel against the REFERENCE module's own output (attention.npz `out`, through the projection) and against
+    the fp32 restatement of the core: 8 bf16 steps of the largest value (q, k, v, P and the result are rounded to
+    8 significant bits; the softmax statistics stay fp32)."""
     from ptv3_hip import ops
-    c = _attn_case(_g(golden_dir, "attention.npz"), 2, dev)
+    from oracle import ptv3 as O
+    c = _attn_case(_g(golden_dir, "attention.npz"), case, dev)
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
     wo, wi = ops.window_maps(to(c["order"]), to(c["inverse"]), to(c["pad"]), to(c["unpad"]))
-    qkv = to(c["qkv"])
-    ref = ops.window_attention(qkv, wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
-    out = ops.window_attention(qkv.bfloat16(), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
+    out = ops.window_attention(to(c["qkv"]).bfloat16(), wo, wi, c["H"], c["K"], (c["C"] // c["H"]) ** -0.5)
     assert out.dtype == torch.bfloat16
-    err = (out.float() - ref).abs().max().item()
-    assert err < 3e-2, err
+    core = O.window_attention_core(torch.from_numpy(c["qkv"]), torch.from_numpy(c["order"]),
+                                   torch.from_numpy(c["inverse"]), torch.from_numpy(c["pad"]),
+                                   torch.from_numpy(c["unpad"]), c["H"], c["K"])
+    assert (out.float().cpu() - core).abs().max().item() < 8 * 2.0 ** -8 * max(1.0, core.abs().max().item())
+    proj = ops.gemm(out, to(c["w"]["proj.weight"].numpy()).bfloat16(), bias=to(c["w"]["proj.bias"].numpy()))
+    gold = torch.from_numpy(c["out"])
+    assert (proj.float().cpu() - gold).abs().max().item() < 8 * 2.0 ** -8 * max(1.0, gold.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_window_attention_k1024_golden(dev, golden_dir, case):
+    """(C, H, K) = (64, 4, 1024) and (512, 32, 1024): the resident-window kernel at the full patch against the reference
+    module's own output, fp32 1e-4 through the projection and bf16 within 8 steps."""
+    from ptv3_hip import ops
+    from oracle import sfc
+    g = _g(golden_dir, "attention_k1024.npz")
+    t = f"a{case}_"
+    C, H, pmax, oi, rpe, K = [int(v) for v in g[t + "cfg"]]
+    off, gc = g[t + "offset"], g[t + "grid_coord"]
+    batch = np.repeat(np.arange(len(off)), np.diff(off, prepend=0))
+    code, order, inverse, _ = sfc.serialization(gc, batch, ORDERS)
+    pad, unpad, _ = sfc.pad_plan(off, K)
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    wo, wi = ops.window_maps(to(order[oi]), to(inverse[oi]), to(pad), to(unpad))
+    w = {k[len(t) + 2:]: to(g[k]) for k in g.files if k.startswith(t + "w_")}
+    gold = torch.from_numpy(g[t + "out"])
+    for dtype, tol in ((torch.float32, FP32_TOL), (torch.bfloat16, 8 * 2.0 ** -8)):
+        qkv = ops.gemm(to(g[t + "feat"]).to(dtype), w["qkv.weight"].to(dtype), bias=w["qkv.bias"])
+        out = ops.window_attention(qkv, wo, wi, H, K, (C // H) ** -0.5)
+        proj = ops.gemm(out, w["proj.weight"].to(dtype), bias=w["proj.bias"])
+        assert (proj.float().cpu() - gold).abs().max().item() < tol * max(1.0, gold.abs().max().item())
 
 
 def test_window_attention_rpe(dev, golden_dir):
@@ -639,8 +671,12 @@ def test_fork_config_vs_oracle(dev, sizes, kind, extent):
     torch.manual_seed(5)
     with torch.no_grad():
         out16 = model({k: v.to(dev) for k, v in data.items()})
-    rel = (out16["pred"].cpu() - ref["pred"]).abs().mean().item() / ref["pred"].abs().mean().item()
-    assert rel < 0.1, rel
+    # 30 blocks of bf16 activations: max-abs error within 64 bf16 steps of the largest logit (the bound of
+    # tests/test_hip_flash_seg.py), and a mean error of a few steps
+    err = (out16["pred"].float().cpu() - ref["pred"]).abs()
+    scale = max(1.0, ref["logits"].abs().max().item())     # pred = (offset, sigmoid(mask logit)) of the head's logits
+    assert err.max().item() < 64 * 2.0 ** -8 * scale, (err.max().item(), scale)
+    assert err.mean().item() < 8 * 2.0 ** -8 * scale, (err.mean().item(), scale)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -716,6 +752,42 @@ def test_offset_keypoint_evaluator_hook(dev):
     assert trainer.comm_info["current_metric_name"] == "mean_dist"
     assert abs(scalars["val/MeanDist"] - mean) < 1e-4 and "val/KP_5_MeanDist" in scalars
     assert any("Keypoint 3 Mean Distance" in s for s in logs)
+
+
+@pytest.mark.parametrize("tag", ["r0", "r1", "r2"])
+def test_offset_keypoint_evaluator_vs_reference_hook(dev, golden_dir, tag):
+    """This package's hook (device totals, two launches per batch) on the batches the REFERENCE's hook was run on in the
+    build container: MeanDist, the per-keypoint means / sample counts and the SaveBest metric it reported."""
+    from pointcept.engines.hooks.builder import HOOKS
+    import types
+    import re
+    g = _g(golden_dir, "evaluator.npz")
+    loader = []
+    for i in range(int(g[tag + "_nbatch"])):
+        b = {k: torch.from_numpy(g[f"{tag}_b{i}_{k}"]) for k in ("coord", "target", "offset")}
+        b["_pred"] = torch.from_numpy(g[f"{tag}_b{i}_pred"])
+        if f"{tag}_b{i}_scale" in g.files:
+            b["scale"] = torch.from_numpy(g[f"{tag}_b{i}_scale"])
+        loader.append(b)
+    hook = HOOKS.build(dict(type="OffsetKeypointEvaluator", num_keypoints=6))
+    logs, scalars = [], {}
+
+    class M:
+        def eval(self):
+            return self
+
+        def __call__(self, d):
+            return {"pred": d["_pred"]}
+    hook.trainer = types.SimpleNamespace(val_loader=loader, model=M(), logger=types.SimpleNamespace(info=logs.append),
+                                         writer=types.SimpleNamespace(add_scalar=lambda k, v, e: scalars.__setitem__(k, v)),
+                                         epoch=0, comm_info={})
+    hook.after_epoch()
+    assert abs(scalars["val/MeanDist"] - float(g[tag + "_mean_dist"])) < 1e-5
+    got = np.array([scalars[f"val/KP_{k}_MeanDist"] for k in range(6)])
+    assert np.allclose(got, g[tag + "_kp_mean_dist"], atol=1e-5)
+    counts = [int(re.search(r"Valid Samples Evaluated: (\d+)", s).group(1)) for s in logs if "Valid Samples" in s]
+    assert counts == g[tag + "_kp_counts"].tolist()
+    assert abs(hook.trainer.comm_info["current_metric_value"] - float(g[tag + "_metric"])) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------

@@ -92,6 +92,44 @@ def test_attention_golden(golden_dir):
             assert (proj - ref).abs().max().item() < 2e-6, i
 
 
+def test_attention_k1024_golden(golden_dir):
+    """the reference's SerializedAttention at (C, H, K) = (64, 4, 1024) and (512, 32, 1024)
+    (tests/golden/make_golden_attention_k1024.py)."""
+    g = _load(golden_dir, "attention_k1024.npz")
+    for i in range(int(g["n_cases"])):
+        t = f"a{i}_"
+        C, H, pmax, oi, rpe, K = [int(v) for v in g[t + "cfg"]]
+        assert K == 1024
+        off, gc = g[t + "offset"], g[t + "grid_coord"]
+        batch = np.repeat(np.arange(len(off)), np.diff(off, prepend=0))
+        code, order, inverse, _ = sfc.serialization(gc, batch, ORDERS)
+        pad, unpad, _ = sfc.pad_plan(off, K)
+        w = {k[len(t) + 2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(t + "w_")}
+        out = O.window_attention(
+            torch.from_numpy(g[t + "feat"]), w["qkv.weight"], w["qkv.bias"], w["proj.weight"], w["proj.bias"],
+            torch.from_numpy(order[oi]), torch.from_numpy(inverse[oi]), torch.from_numpy(pad),
+            torch.from_numpy(unpad), H, K, grid_coord=torch.from_numpy(gc), patch_size_cfg=pmax)
+        ref = torch.from_numpy(g[t + "out"])
+        assert (out - ref).abs().max().item() < 5e-6 * max(1.0, ref.abs().max().item()), i
+
+
+def test_evaluator_oracle_matches_reference_hook(golden_dir):
+    """oracle/keypoints.py::evaluator_totals against what the REFERENCE's OffsetKeypointEvaluator hook reported on the
+    same seeded batches (tests/golden/make_golden_evaluator.py ran engines/hooks/offset_keypoint_evaluator.py:19-123)."""
+    from oracle import keypoints as KO
+    g = _load(golden_dir, "evaluator.npz")
+    for tag in ("r0", "r1", "r2"):
+        tot = np.zeros(14)
+        for i in range(int(g[tag + "_nbatch"])):
+            b = {k: torch.from_numpy(g[f"{tag}_b{i}_{k}"]) for k in ("coord", "target", "offset", "pred")}
+            scale = torch.from_numpy(g[f"{tag}_b{i}_scale"]) if f"{tag}_b{i}_scale" in g.files else None
+            tot += np.array(KO.evaluator_totals(b["pred"], b["target"], b["coord"], b["offset"], scale, 6))
+        assert abs(tot[0] / (tot[1] + 1e-6) - float(g[tag + "_mean_dist"])) < 1e-6
+        assert np.array_equal(tot[8:].astype(int), g[tag + "_kp_counts"])
+        assert np.allclose(tot[2:8] / (tot[8:] + 1e-6), g[tag + "_kp_mean_dist"], atol=1e-6)
+        assert abs(float(g[tag + "_metric"]) + float(g[tag + "_mean_dist"])) < 1e-12
+
+
 def test_full_model_golden(golden_dir):
     g = _load(golden_dir, "ptv3_tiny.npz")
     sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd_")}
