@@ -1,7 +1,6 @@
 // Argument blocks and register-chain helpers shared by the fused halves of Block.forward
 // (block_fused.hip: wave-local / cooperative variants; block_wide.hip: the LDS-DMA weight-streaming variant).
 #pragma once
-#include <mutex>
 #include "common.h"
 
 namespace ptv3 {
@@ -63,32 +62,6 @@ __device__ __forceinline__ void row_norm(const f32x4* v, float eps, float& mean,
 #pragma unroll
     for (int r = 0; r < 4; ++r) { float d = v[j][r] - mean; q += d * d; }
   rstd = rsqrtf(groups_sum(q) * (1.0f / (16 * NT)) + eps);
-}
-
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: set it once per (function,
-// device), under a lock (a process may drive several GPUs, and several host threads one GPU).
-inline void ensure_dynamic_lds(const void* fn, int bytes) {
-  constexpr int MAX_DEV = 64, MAX_FN = 256;
-  static std::mutex mu;
-  static const void* fns[MAX_FN];
-  static int maxb[MAX_FN][MAX_DEV];
-  static int nfn = 0;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    return;
-  }
-  std::lock_guard<std::mutex> lock(mu);
-  int i = 0;
-  while (i < nfn && fns[i] != fn) ++i;
-  if (i == nfn) {
-    if (nfn == MAX_FN) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
-    fns[nfn++] = fn;
-  }
-  if (maxb[i][dev] < bytes) {
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    maxb[i][dev] = bytes;
-  }
 }
 
 // block_wide.hip: the weight-streaming variant for c in {128, 256} at large m

@@ -701,12 +701,7 @@ static void launch_tail(const TailArgs& a, int c, hipStream_t s) {
   const size_t wb = tail_wlds_bytes(c, a.hidden, sizeof(T));
   const int64_t nblocks = cdiv(a.m, 64 * RT);
   if (wb <= 96 * 1024) {
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_tail_kernel<T, NT, RT, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr = true;
-    }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&block_tail_kernel<T, NT, RT, true>), 96 * 1024);
     // weights resident per workgroup: a few workgroups per CU, each walking many row blocks
     const int64_t grid = std::min<int64_t>(nblocks, 2 * 256);
     hipLaunchKernelGGL((block_tail_kernel<T, NT, RT, true>), dim3((unsigned)grid), dim3(256), wb, s, a);
@@ -786,12 +781,7 @@ static void launch_head_coop(const HeadArgs& a, hipStream_t s) {
 }
 template <typename T, int C>
 static void launch_tail_coop(const TailArgs& a, hipStream_t s) {
-  static bool attr = false;  // > 64 KB of dynamic LDS needs the opt-in, once per instantiation
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&block_tail_coop_kernel<T, C, 4>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&block_tail_coop_kernel<T, C, 4>), 160 * 1024);
   hipLaunchKernelGGL((block_tail_coop_kernel<T, C, 4>), dim3((unsigned)cdiv(a.m, 16)), dim3(64 * Coop<C>::NW),
                      coop_tail_lds(C, 4 * C, sizeof(T)), s, a);
 }
@@ -835,8 +825,7 @@ extern "C" int ptv3_mlp2(const void* x, const void* w1, const float* b1, const f
   dim3 grid((unsigned)(wlds ? std::min<int64_t>(nblocks, 2 * 256) : nblocks)), block(256);
 #define MLP2_GO(KERNEL_T, KERNEL_F)                                                               \
   if (wlds) {                                                                                     \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL_T), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              128 * 1024);                                                        \
+    ensure_dynamic_lds(reinterpret_cast<const void*>(&KERNEL_T), 128 * 1024);                     \
     hipLaunchKernelGGL(KERNEL_T, grid, block, wb, s, a);                                          \
   } else {                                                                                        \
     hipLaunchKernelGGL(KERNEL_F, grid, block, 0, s, a);                                           \

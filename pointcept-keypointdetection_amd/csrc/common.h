@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 #define PTV3_OK 0
 #define PTV3_ERR_ARG 1
@@ -149,6 +150,32 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   unsigned q = nwg / nx, r = nwg % nx;
   unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + slot;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: set it once per (function,
+// device), under a lock (a process may drive several GPUs, and several host threads one GPU).
+inline void ensure_dynamic_lds(const void* fn, int bytes) {
+  constexpr int MAX_DEV = 64, MAX_FN = 256;
+  static std::mutex mu;
+  static const void* fns[MAX_FN];
+  static int maxb[MAX_FN][MAX_DEV];
+  static int nfn = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    return;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  int i = 0;
+  while (i < nfn && fns[i] != fn) ++i;
+  if (i == nfn) {
+    if (nfn == MAX_FN) { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); return; }
+    fns[nfn++] = fn;
+  }
+  if (maxb[i][dev] < bytes) {
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    maxb[i][dev] = bytes;
+  }
 }
 
 }  // namespace ptv3

@@ -238,8 +238,10 @@ knn_cells_kernel(int m, int nsample, const float* __restrict__ xyz, const float*
         pheap_offer<KPL>(bd, bi, nsample, has, d, i, tau_d, tau_i, lane);
       }
     }
-    // everything outside shell r is farther than r cells (a hair less: the cell of a point is a rounded division)
-    const float reach = (float)r * cell * 0.9999f;
+    // everything outside shell r is farther than r cells - less the rounding of the cell assignment: a point's cell
+    // is floor((x - lo) / cell) in fp32 (two roundings, each 2^-24 relative to a quotient below the 65536-cell grid
+    // extent), so a point can sit up to 2 * 65536 * 2^-23 = 0.016 cells across a boundary, on either end of the pair
+    const float reach = ((float)r - 0.04f) * cell;
     done = tau_d < 1e10f && tau_d < reach * reach;
   }
   if (!done) {

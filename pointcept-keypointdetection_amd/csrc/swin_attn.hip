@@ -201,12 +201,7 @@ static int launch_swin(const void* q, const void* k, const void* v, const float*
     set_error("swin_attn: %d tokens x head_dim %d needs %zu bytes of LDS", max_tokens, D, lds);
     return PTV3_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&swin_attn_kernel<T, D, S>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&swin_attn_kernel<T, D, S>), 160 * 1024);
   hipLaunchKernelGGL((swin_attn_kernel<T, D, S>), dim3((unsigned)nwin, (unsigned)heads), dim3(SWIN_WAVES * 64), lds, s,
                      (const T*)q, (const T*)k, (const T*)v, qt, kt, vt, tab, n2n, w_start, crse, (T*)out, heads,
                      max_tokens);

@@ -535,12 +535,7 @@ template <typename T> struct FullArgs {
 
 template <typename T, int ND, int RPE, int QT>
 static void launch_full(const FullArgs<T>& a) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, RPE, QT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&window_attn_full_kernel<T, ND, RPE, QT>), 160 * 1024);
   const int QB = a.waves * QT * 16;
   const int qsplit = (a.K + QB - 1) / QB;
   const unsigned nwg = (unsigned)a.nwin * a.H * qsplit;

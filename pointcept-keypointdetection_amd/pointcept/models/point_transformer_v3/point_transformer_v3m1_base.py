@@ -744,8 +744,11 @@ class PointTransformerV3(PointModule):
                             name=f"block{i}")
                 self.dec.add(module=dec, name=f"dec{s}")
 
+    _warned_fp16 = False
+
     def resolve_dtype(self):
         if self.compute_dtype is not None:
+            self.effective_dtype = self.compute_dtype
             return self.compute_dtype
         if torch.is_autocast_enabled():
             # amp_dtype="float16" is the reference's default (configs/_base_/default_runtime.py:19) and means "16-bit
@@ -753,7 +756,16 @@ class PointTransformerV3(PointModule):
             # range, so the GradScaler the trainer wraps around fp16 runs (engines/train.py:201-241) never sees an
             # overflow - and hand results back in fp32 at the model boundary (pred / seg_logits / loss).
             dt = torch.get_autocast_gpu_dtype()
-            return torch.bfloat16 if dt in (torch.bfloat16, torch.float16) else torch.float32
+            if dt == torch.float16 and not PointTransformerV3._warned_fp16:
+                # said once, and visible afterwards as `backbone.effective_dtype` (what a trainer can log): the arithmetic
+                # is NOT what the config names - 8 mantissa bits instead of 11 - and a GradScaler has nothing to protect
+                import warnings
+                warnings.warn("PT-v3m1 (MI355X HIP path): autocast float16 is computed in bfloat16 (same width, fp32 exponent "
+                              "range); set amp_dtype='bfloat16' to make the config say what runs", stacklevel=2)
+                PointTransformerV3._warned_fp16 = True
+            self.effective_dtype = torch.bfloat16 if dt in (torch.bfloat16, torch.float16) else torch.float32
+            return self.effective_dtype
+        self.effective_dtype = torch.float32
         return torch.float32
 
     def _plan_pooling(self, point):

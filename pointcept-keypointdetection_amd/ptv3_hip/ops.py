@@ -870,9 +870,10 @@ def knn_query_cells(nsample, xyz, offset, new_xyz, new_offset, cell=None):
         cell = max(r_surf, min(r_vol, 4.0 * r_surf), 1e-9)
     cell = float(cell)
     cell_t = torch.full((), cell, dtype=torch.float32, device=dev)
-    base = torch.floor(lo_f / cell_t)
-    csrc = (torch.floor(xyz / cell_t) - base).int()
-    cq = (torch.floor(new_xyz / cell_t) - base).int()
+    # cells relative to the bounding box's corner: the quotient stays below the grid extent wherever the scene sits
+    # (absolute coordinates far from the origin lose the cell boundary to fp32 rounding: |x / cell| 2^-24 cells)
+    csrc = torch.floor((xyz - lo_f) / cell_t).int()
+    cq = torch.floor((new_xyz - lo_f) / cell_t).int()
     extent = int(torch.maximum(csrc.amax(), cq.amax()))
     if extent >= 65536:
         raise ValueError(f"knn_query_cells: {extent + 1} cells of edge {cell} along one axis (limit 65536): use a larger cell")

@@ -131,3 +131,80 @@ def test_sync_batchnorm_two_ranks_match_one_global_batch(tmp_path):
     assert close(r[0]["dw"] + r[1]["dw"], bn.weight.grad, 1e-4) and close(r[0]["db"] + r[1]["db"], bn.bias.grad, 1e-4)
     for k in range(2):
         assert close(r[k]["rm"], bn.running_mean) and close(r[k]["rv"], bn.running_var)
+
+
+# ---------------------------------------------------------------- DDP bucket views + fused AdamW, two full steps
+def _groups(model):
+    return [dict(params=[p for n, p in model.named_parameters() if "block" in n], lr=2e-4),
+            dict(params=[p for n, p in model.named_parameters() if "block" not in n])]
+
+
+def _opt_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _paths()
+    from ptv3_hip.optim import FusedAdamW
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    model = _model().to(dev).train()
+    model.backbone.compute_dtype = torch.bfloat16
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=False,
+                                                    gradient_as_bucket_view=True)      # what bench.py --mode train does
+    opt = FusedAdamW(_groups(model), lr=2e-3, weight_decay=5e-3, shadow_dtype=torch.bfloat16)
+    data = _scene(rank, dev)
+    grads = []
+    for it in range(2):
+        opt.zero_grad()                                   # set_to_none: the bucket views come back in backward
+        torch.manual_seed(5 + it)
+        ddp(data)["loss"].backward()
+        grads.append([p.grad.detach().float().cpu().clone() for p in model.parameters()])
+        opt.step()
+    torch.cuda.synchronize()
+    torch.save(dict(w=[p.detach().cpu() for p in model.parameters()], g=grads), os.path.join(out_dir, f"o{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_bucket_views_with_fused_adamw_two_steps(tmp_path):
+    """The combination `bench.py --mode train --gpus N` runs: DistributedDataParallel(gradient_as_bucket_view=True) +
+    FusedAdamW (gradient ADDRESSES as launch arguments, zero_grad(set_to_none=True), two parameter groups, bf16
+    shadows), two full steps on two ranks.  Both ranks must end with the same weights, and those weights must be what
+    torch.optim.AdamW gives in ONE process that is fed the rank-averaged gradients the ranks saw
+    (engines/defaults.py:22-43,136)."""
+    assert torch.cuda.is_available()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_opt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), f"o{k}.pt"), weights_only=True) for k in range(2)]
+    for a, b in zip(r[0]["w"], r[1]["w"]):
+        assert torch.equal(a, b)                           # identical replicas after two steps
+    for it in range(2):                                   # DDP left the SAME averaged gradient on both ranks
+        for a, b in zip(r[0]["g"][it], r[1]["g"][it]):
+            assert torch.equal(a, b)
+    model = _model().train()                              # CPU replica of the initial weights
+    ref_opt = torch.optim.AdamW(_groups(model), lr=2e-3, weight_decay=5e-3)
+    for it in range(2):
+        for p, g in zip(model.parameters(), r[0]["g"][it]):
+            p.grad = g.clone()
+        ref_opt.step()
+    for p, w in zip(model.parameters(), r[0]["w"]):
+        assert (p.detach() - w).abs().max().item() <= 1e-6 + 1e-5 * p.detach().abs().max().item()
+
+
+def test_bench_train_two_ranks_self_launch(tmp_path):
+    """`bench.py --mode train --gpus 2` through its OWN launcher (spawn before any GPU call, tcp rendezvous on
+    127.0.0.1, DDP, fused AdamW, max-over-ranks timing), both ranks on the one GPU of the test box over gloo
+    (PTV3_BENCH_BACKEND: RCCL needs a device per rank) - the real train path before the first 8-GPU run."""
+    import json
+    import subprocess
+    env = dict(os.environ, PTV3_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train", "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--points", "20000", "--no-kernel-events"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["value"] > 0
+    assert line["allreduce_probe"]["ranks"] == 2 and line["config"]["parallelism"].startswith("dp2")
+    assert line["final_loss"] == line["final_loss"]      # not NaN

@@ -197,6 +197,31 @@ def test_knn_query_cells_against_the_reference_scan(dev, nsample, kind):
         assert set(got_i[r][inside].tolist()) == set(wi[r][wd[r] < got_d[r][real][-1]].tolist())
 
 
+@pytest.mark.parametrize("shift,cell", [(250.0, 0.05), (2500.0, 0.05), (40000.0, 1.0)])
+def test_knn_query_cells_far_from_the_origin(dev, shift, cell):
+    """Coordinates far from the origin (|x / cell| = 5e3 .. 5e4: an outdoor scene in metres at a 5 cm cell, Swin3D voxel
+    units past 1000): the cell of a point is taken relative to the bounding box's corner and the shell test keeps a
+    margin for its rounding, so the nearest neighbour is still the scan's, bit for bit (nsample = 1 has no tie freedom)
+    and for nsample = 8 the distances are."""
+    from ptv3_hip import ops
+    from oracle import pointops as OP
+    rng = np.random.default_rng(int(shift))
+    n, m = 6000, 3000
+    span = 600 * cell                                     # a few hundred cells across
+    xyz = (rng.uniform(0, span, size=(n, 3)) + shift).astype(np.float32)
+    new_xyz = (rng.uniform(0, span, size=(m, 3)) + shift).astype(np.float32)
+    offset, new_offset = np.array([n], np.int32), np.array([m], np.int32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for nsample in (1, 8):
+        want_i, want_d = OP.knn_query(nsample, xyz, offset, new_xyz, new_offset)
+        got_i, got_d = ops.knn_query_cells(nsample, t(xyz), t(offset), t(new_xyz), t(new_offset), cell)
+        got_i, got_d = got_i.cpu().numpy(), got_d.cpu().numpy()
+        wi, wd = _sorted_pairs(want_i, want_d)
+        assert np.array_equal(got_d, wd)
+        if nsample == 1:
+            assert np.array_equal(got_i, want_i)
+
+
 def test_knn_rejects_offsets_that_do_not_end_at_the_row_counts(dev):
     """The kernels trust the scene ends; a last entry beyond the arrays would read past them."""
     import pointops

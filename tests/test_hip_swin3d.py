@@ -454,7 +454,11 @@ def test_offset_keypoint_swin3d_trains(dev):
     for _ in range(8):
         opt.zero_grad()
         out = model(dict(data))
-        assert set(out) == {"loss"}
+        # the curves the reference's InformationWriter logs for this class (offset_keypoint_swin3d.py:92-124)
+        assert set(out) == {"loss", "train/cls_loss", "train/reg_loss", "train/offset_l1_err", "train/mean_dist"} | \
+            {f"train/kp{i}_dist" for i in range(6)}
+        assert all(v.dim() == 0 and not v.requires_grad for k, v in out.items() if k != "loss")
+        assert abs(out["train/mean_dist"].item() - sum(out[f"train/kp{i}_dist"].item() for i in range(6)) / 6) < 1e-5
         out["loss"].backward()
         opt.step()
         losses.append(out["loss"].item())
