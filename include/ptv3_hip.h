@@ -498,6 +498,9 @@ int ptv3_keypoint_aggregate(const float* coord, const float* pred, const int64_t
  * neighbour), algorithmic bytes and launch count since enable / the last collect. */
 int ptv3_profile_enable(int on);
 int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches);
+/* Flops of the NEXT bracketed launch, for kernels whose work is decided by device data the entry point does not read
+ * back (ptv3_swin_attn_fwd: the pair count sum_w len_w^2 lives in w_start); ignored while profiling is off. */
+int ptv3_profile_hint_flops(double flops);
 /* the same records by KERNEL (one launch per bracket): arrays of ptv3_profile_kernel_count() entries, entry i is the
  * kernel ptv3_profile_kernel_name(i) (gemm_kernel 64 / 32 channel tiles and gemm_big_kernel each split into their
  * dense and gathered = sparse-conv launches, the fused block halves, mlp2, the two window-attention kernels).  Does not

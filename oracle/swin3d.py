@@ -195,7 +195,9 @@ def _offset_of(batch, nb):
 
 
 class Swin3DOracle:
-    """Functional restatement of Swin3DUNet.forward for knn_down=True, stem_transformer=True.  Sparse tensors are
+    """Functional restatement of Swin3DUNet.forward (knn_down True | False: GridKNNDownsample | GridDownsample,
+    swin3d_layers.py:246-318; stem_transformer True | False: MinkConvBNRelu | + MinkResBlock and a downsample in front
+    of the first attention stage, swin3d_v1m1_base.py:69-85, 213-216).  Sparse tensors are
     (coords int (n,4) at a tensor stride, feat (n,C), cfeat (n, 4 + signals)) triples numbered in sorted
     (batch, x, y, z) order; see the header of this file and of the product's swin3d_v1m1_base.py for the choices the
     absent libraries leave open (tap order of the stem kernel, Euclidean KNN distance, the GridCoordsDown tie rule)."""
@@ -246,12 +248,32 @@ class Swin3DOracle:
         np.minimum.at(pick, cell, np.where(near, np.arange(len(dist)), len(dist)))
         new_cfeat = cfeat[pick]
         new_offset = _offset_of(new_coords[:, 0], len(offset))
+        if not self.cfg.get("knn_down", True):
+            # GridDownsample (:246-272): LayerNorm -> Linear (no bias) -> maximum over the voxels of each cell
+            y = self._lin(_ln(feat, self.sd[pre + "norm.norm.weight"], self.sd[pre + "norm.norm.bias"]), pre + "linear.linear.")
+            new_feat = np.full((m, y.shape[1]), -np.inf)
+            np.maximum.at(new_feat, cell, y)
+            return new_coords, new_stride, new_feat.astype(np.float32), new_cfeat, new_offset
         y = self._lin(_ln(feat, self.sd[pre + "norm.weight"], self.sd[pre + "norm.bias"]), pre + "linear.")
         idx, _ = OP.knn_query(16, np.ascontiguousarray(cfeat[:, 1:4]), offset,
                               np.ascontiguousarray(new_cfeat[:, 1:4]), new_offset)
         idx = np.where(idx < 0, idx[:, :1], idx)
         new_feat = y[idx].max(axis=1).astype(np.float32)
         return new_coords, new_stride, new_feat, new_cfeat, new_offset
+
+    def _conv3(self, x, coords, key):
+        """3x3x3 convolution on the occupied voxels, kernel[t] at offset t = (dx+1) + 3 (dy+1) + 9 (dz+1), no bias"""
+        import torch
+        from .ptv3 import subm_conv3d
+        kern = self.sd[key]
+        cin, cout = kern.shape[1:]
+        w = np.zeros((cout, 3, 3, 3, cin), np.float32)
+        for a in range(3):
+            for b in range(3):
+                for c in range(3):
+                    w[:, a, b, c, :] = kern[a + 3 * b + 9 * c].T
+        return subm_conv3d(torch.from_numpy(np.ascontiguousarray(x, np.float32)), torch.from_numpy(coords),
+                           torch.from_numpy(w)).numpy()
 
     def _up(self, pre, deep, shallow, heads, ws):
         from . import pointops as OP
@@ -288,21 +310,25 @@ class Swin3DOracle:
         ncf = coord_feat.shape[1] + 4
         coords, stride, cfeat, x = uniq.astype(np.int64), 1, mean[:, :ncf], mean[:, ncf:]
         off = _offset_of(coords[:, 0], len(offset))
-        # stem: 3x3x3 convolution on the occupied voxels, kernel[t] at offset t = (dx+1) + 3 (dy+1) + 9 (dz+1)
-        kern = sd["stem_layer.conv_layers.0.kernel"]
-        cin, cout = kern.shape[1:]
-        w = np.zeros((cout, 3, 3, 3, cin), np.float32)
-        for a in range(3):
-            for b in range(3):
-                for c in range(3):
-                    w[:, a, b, c, :] = kern[a + 3 * b + 9 * c].T
-        y = subm_conv3d(torch.from_numpy(x), torch.from_numpy(coords), torch.from_numpy(w)).numpy()
-        x = np.maximum(_bn(y, sd, "stem_layer.conv_layers.1.bn.", 1e-5), 0).astype(np.float32)
-        trace["stem"] = x
+        stem_tr = cfg.get("stem_transformer", True)
+        sp = "stem_layer." if stem_tr else "stem_layer.0."
+        x = np.maximum(_bn(self._conv3(x, coords, sp + "conv_layers.0.kernel"), sd, sp + "conv_layers.1.bn.", 1e-5), 0)
+        x = x.astype(np.float32)
         skips = []
         nl = cfg["num_layers"]
-        for i in range(nl):
-            pre = f"layers.{i}."
+        start = 0
+        if not stem_tr:
+            # MinkResBlock (mink_layers.py:115-155), then the model's own downsample in front of stage 1 (:213-216)
+            r = "stem_layer.1."
+            y = np.maximum(_bn(self._conv3(x, coords, r + "conv1.kernel"), sd, r + "norm1.bn.", 1e-5), 0)
+            y = _bn(self._conv3(y, coords, r + "conv2.kernel"), sd, r + "norm2.bn.", 1e-5)
+            x = np.maximum(y + x, 0).astype(np.float32)
+            skips.append((coords, stride, x, cfeat, off))
+            coords, stride, x, cfeat, off = self._down("downsample.", coords, stride, x, cfeat, off, cfg["down_stride"])
+            start = 1
+        trace["stem"] = x
+        for i in range(start, nl):
+            pre = f"layers.{i - start}."
             x = self._stage(pre, x, coords, stride, cfeat, cfg["depths"][i], cfg["num_heads"][i], cfg["window_sizes"][i])
             skips.append((coords, stride, x, cfeat, off))
             trace[f"layer{i}"] = x

@@ -12,8 +12,10 @@ static const char* const g_kernel_names[PK_KERNELS] = {
     "gemm_kernel<32ch> gather (sparse conv)", "gemm_big_kernel dense", "gemm_big_kernel gather (sparse conv)",
     "block_head_kernel", "block_tail_kernel", "block_head_coop_kernel", "block_tail_coop_kernel", "mlp2_kernel",
     "window_attn_full_kernel", "window_attn_kernel", "block_head_wide_kernel", "block_tail_wide_kernel",
-    "conv_tile_kernel (sparse conv)", "gemm_tn_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel"};
+    "conv_tile_kernel (sparse conv)", "gemm_tn_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
+    "swin_attn_kernel"};
 static bool g_on = false;
+static double g_hint_flops = -1.0;   // flops of the NEXT bracket, set by the caller that knows them (ptv3_profile_hint_flops)
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
 static unsigned long long* g_slots = nullptr;
@@ -41,6 +43,7 @@ int prof_begin(hipStream_t s, int family, double flops, double bytes, const int3
                double flops_per_valid) {
   if (!g_on) return -1;
   static const int default_kernel[PROF_FAMILIES] = {PK_GEMM64_DENSE, PK_GEMM64_CONV, PK_ATTN_FULL, PK_GEMM_TN};
+  if (g_hint_flops >= 0.0) { flops = g_hint_flops; g_hint_flops = -1.0; }
   ProfRec r{family, flops, bytes, flops_per_valid, get_event(), get_event(), -1, default_kernel[family]};
   if (nbr && g_slots && g_nslots < MAX_SLOTS) {
     r.slot = g_nslots++;
@@ -74,6 +77,11 @@ extern "C" int ptv3_profile_enable(int on) {
     g_recs.clear();
   }
   g_on = on != 0;
+  return PTV3_OK;
+}
+
+extern "C" int ptv3_profile_hint_flops(double flops) {
+  g_hint_flops = flops;
   return PTV3_OK;
 }
 

@@ -13,6 +13,7 @@
 // lanes across the keys, table rows come from global memory (the per-head slice of all tables is tens of KB and
 // stays in L2 / the vector L1).  fp32 arithmetic throughout; bf16 only as the storage type of q, k, v, out.
 #include "common.h"
+#include "profile.h"
 #include "../../include/ptv3_hip.h"
 
 namespace ptv3 {
@@ -279,9 +280,18 @@ extern "C" int ptv3_swin_attn_fwd(const void* q, const void* k, const void* v, c
   for (int c = num_axes; c < SWIN_MAX_AXES; ++c) { tab.start[c] = 0; tab.rows[c] = 2; }
   if (num_windows <= 0 || n <= 0) return PTV3_OK;
   hipStream_t s = (hipStream_t)stream;
+  // algorithmic work: (1 + 3 S) 2 D flops per (query, key) pair and head - the pair count lives in w_start on the
+  // device; a caller that knows it says so through ptv3_profile_hint_flops - and q, k, v, out once each
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_WINDOW_ATTN, 0.0, 4.0 * (double)n * heads * head_dim * esz + 12.0 * n, nullptr, 0, 0.0);
+  prof_kernel(prof, PK_SWIN_ATTN);
+  int rc;
   if (dtype == PTV3_F32)
-    return dispatch_dim<float>(head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab, (const long long*)n2n,
-                               w_start, num_windows, n_crse, out, heads, max_tokens, s);
-  return dispatch_dim<__bf16>(head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab, (const long long*)n2n,
+    rc = dispatch_dim<float>(head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab, (const long long*)n2n,
+                             w_start, num_windows, n_crse, out, heads, max_tokens, s);
+  else
+    rc = dispatch_dim<__bf16>(head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab, (const long long*)n2n,
                               w_start, num_windows, n_crse, out, heads, max_tokens, s);
+  prof_end(prof, s);
+  return rc;
 }

@@ -106,29 +106,110 @@ class _ConvBNRelu(nn.Module):
                                          nn.ReLU(inplace=True))
 
     def forward(self, level):
-        conv, bn = self.conv_layers[0], self.conv_layers[1].bn
-        x = level.feat
-        gran = ops.k_granule(x.dtype)
-        cin_pad = (conv.in_channels + gran - 1) // gran * gran
-        if cin_pad != conv.in_channels:
-            x = torch.nn.functional.pad(x, (0, cin_pad - conv.in_channels)).contiguous()
-        k = conv.kernel_size
-        # this package's gather order is tap d = (a k + b) k + c with (a, b, c) the x, y, z offsets; the kernel is read
-        # x-fastest (see the module docstring)
-        a, b, c = torch.meshgrid(torch.arange(k), torch.arange(k), torch.arange(k), indexing="ij")
-        t_me = (a + k * b + k * k * c).reshape(-1).to(conv.kernel.device)
-        w = conv.kernel.detach()[t_me]                                   # (27 taps in gather order, cin, cout)
-        w = torch.nn.functional.pad(w, (0, 0, 0, cin_pad - conv.in_channels))
-        w = w.permute(2, 0, 1).reshape(conv.out_channels, -1).to(x.dtype).contiguous()
-        nbr, _ = ops.subm_neighbors(level.coords, k)
-        if self.training:
-            # taped: the kernel re-indexed to this package's tap order as a differentiable view, batch-statistic BN
-            w5 = conv.kernel[t_me].permute(2, 0, 1).reshape(conv.out_channels, k, k, k, conv.in_channels)
-            level.feat = bn(A.subm_conv(level.feat, w5, None, nbr), act=ops.ACT_RELU)
-            return level
-        scale, shift = bn.folded()
-        level.feat = ops.gemm(x, w, nbr=nbr, kvol=k ** 3, bn_scale=scale, bn_shift=shift, act=ops.ACT_RELU)
+        level.feat = _conv3_bn(level.coords, level.feat, self.conv_layers[0], self.conv_layers[1].bn, ops.ACT_RELU,
+                               self.training)
         return level
+
+
+def _conv3_bn(coords, x, conv, bn, act, training, res=None):
+    """MinkowskiConvolution (kernel (k^3, cin, cout), no bias) -> MinkowskiBatchNorm [-> act] [+ res] on the occupied
+    voxels `coords`: ptv3_subm_neighbors + one gathered ptv3_gemm with the BatchNorm folded (eval), or the taped
+    Functions with batch statistics (training)."""
+    gran = ops.k_granule(x.dtype)
+    cin_pad = (conv.in_channels + gran - 1) // gran * gran
+    k = conv.kernel_size
+    # this package's gather order is tap d = (a k + b) k + c with (a, b, c) the x, y, z offsets; the kernel is read
+    # x-fastest (see the module docstring)
+    a, b, c = torch.meshgrid(torch.arange(k), torch.arange(k), torch.arange(k), indexing="ij")
+    t_me = (a + k * b + k * k * c).reshape(-1).to(conv.kernel.device)
+    nbr, _ = ops.subm_neighbors(coords, k)
+    if training:
+        # taped: the kernel re-indexed to this package's tap order as a differentiable view, batch-statistic BN
+        w5 = conv.kernel[t_me].permute(2, 0, 1).reshape(conv.out_channels, k, k, k, conv.in_channels)
+        y = bn(A.subm_conv(x, w5, None, nbr), act=act)
+        return y if res is None else y + res
+    if cin_pad != conv.in_channels:
+        x = torch.nn.functional.pad(x, (0, cin_pad - conv.in_channels)).contiguous()
+    w = conv.kernel.detach()[t_me]                                   # (27 taps in gather order, cin, cout)
+    w = torch.nn.functional.pad(w, (0, 0, 0, cin_pad - conv.in_channels))
+    w = w.permute(2, 0, 1).reshape(conv.out_channels, -1).to(x.dtype).contiguous()
+    scale, shift = bn.folded()
+    return ops.gemm(x, w, nbr=nbr, kvol=k ** 3, bn_scale=scale, bn_shift=shift, act=act, res=res)
+
+
+class MinkResBlock(nn.Module):
+    """mink_layers.MinkResBlock (:115-155): conv1 -> norm1 -> ReLU -> conv2 -> norm2 -> (+ input) -> ReLU, both
+    convolutions 3^3 on the occupied voxels without bias (the `stem_transformer=False` stem, swin3d_v1m1_base.py:69-85)."""
+
+    def __init__(self, in_channels, out_channels, stride=1, dilation=1):
+        super().__init__()
+        assert stride == 1 and dilation == 1 and in_channels == out_channels, "only the stem configuration of Swin3DUNet"
+        self.conv1 = _ConvBNRelu._Conv(in_channels, out_channels, 3)
+        self.norm1 = _ConvBNRelu._BN(out_channels)
+        self.conv2 = _ConvBNRelu._Conv(out_channels, out_channels, 3)
+        self.norm2 = _ConvBNRelu._BN(out_channels)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, level):
+        x = level.feat
+        y = _conv3_bn(level.coords, x, self.conv1, self.norm1.bn, ops.ACT_RELU, self.training)
+        y = _conv3_bn(level.coords, y, self.conv2, self.norm2.bn, ops.ACT_NONE, self.training, res=x)   # out += residual
+        if self.training:
+            level.feat = A.activation(y, ops.ACT_RELU)
+        else:
+            c = y.shape[1]
+            one, zero = torch.ones(c, device=y.device), torch.zeros(c, device=y.device)
+            level.feat = ops.affine_act(y, one, zero, ops.ACT_RELU)
+        return level
+
+
+def _pool_cells(level, stride):
+    """Cells of `stride` voxels per axis (MinkowskiMaxPooling's output coordinates) and GridCoordsDown (:180-231): the
+    member nearest (over ALL carried columns, :203-206) to its cell's mean carries the cell's signals."""
+    new_stride = level.stride * stride
+    order, cluster, seg_start, m = _segments(_key(level.coords, new_stride))
+    head = order[seg_start[:-1].long()]
+    coords = (level.coords[head] // new_stride * new_stride).clone()
+    coords[:, 0] = level.coords[head, 0]
+    mean = _segment_mean(level.cfeat, order, seg_start, m)
+    dist = (mean[cluster] - level.cfeat).pow(2).sum(1).sqrt()
+    n = dist.shape[0]
+    best = torch.full((m,), float("inf"), device=dist.device).scatter_reduce(0, cluster, dist, "amin")
+    near = dist <= best[cluster] * (1 + 1e-4) + 1e-12
+    ids = torch.where(near, torch.arange(n, device=dist.device), torch.full_like(cluster, n))
+    pick = torch.full((m,), n, device=dist.device, dtype=torch.long).scatter_reduce(0, cluster, ids, "amin")
+    cfeat = level.cfeat[pick].contiguous()
+    offset = _offsets(coords[:, 0], level.offset.shape[0])
+    return coords.int().contiguous(), new_stride, cfeat, offset, order, seg_start, m
+
+
+class GridDownsample(nn.Module):
+    """swin3d_layers.py:246-272 (`knn_down=False`): SparseTensorLayerNorm -> SparseTensorLinear (no bias) ->
+    MinkowskiMaxPooling(kernel_size = stride): the maximum over the voxels of each cell; coordinates and signal carrier
+    as GridKNNDownsample."""
+
+    class _Norm(nn.Module):
+        def __init__(self, dim):
+            super().__init__()
+            self.norm = LayerNorm(dim)
+
+    class _Linear(nn.Module):
+        def __init__(self, cin, cout):
+            super().__init__()
+            self.linear = Linear(cin, cout, bias=False)
+
+    def __init__(self, in_channels, out_channels, kernel_size=2, stride=2):
+        super().__init__()
+        assert kernel_size == stride, "Swin3DUNet builds its downsample with kernel_size = stride"
+        self.kernel_size, self.stride, self.in_channels, self.out_channels = kernel_size, stride, in_channels, out_channels
+        self.norm = self._Norm(in_channels)
+        self.linear = self._Linear(in_channels, out_channels)
+
+    def forward(self, level):
+        coords, new_stride, cfeat, offset, order, seg_start, m = _pool_cells(level, self.stride)
+        y = self.linear.linear(self.norm.norm(level.feat))
+        feat = A.segment_max(y, order, seg_start, m) if self.training else ops.pool_max(y, order, seg_start, m)
+        return _Level(coords, new_stride, feat, cfeat, offset)
 
 
 class GridKNNDownsample(nn.Module):
@@ -141,22 +222,7 @@ class GridKNNDownsample(nn.Module):
         self.linear = Linear(in_channels, out_channels, bias=False)
 
     def forward(self, level):
-        new_stride = level.stride * self.stride
-        order, cluster, seg_start, m = _segments(_key(level.coords, new_stride))
-        head = order[seg_start[:-1].long()]
-        coords = (level.coords[head] // new_stride * new_stride).clone()
-        coords[:, 0] = level.coords[head, 0]
-        # GridCoordsDown: the member nearest (over ALL carried columns, :203-206) to its cell's mean carries the cell
-        mean = _segment_mean(level.cfeat, order, seg_start, m)
-        dist = (mean[cluster] - level.cfeat).pow(2).sum(1).sqrt()
-        n = dist.shape[0]
-        best = torch.full((m,), float("inf"), device=dist.device).scatter_reduce(0, cluster, dist, "amin")
-        near = dist <= best[cluster] * (1 + 1e-4) + 1e-12
-        ids = torch.where(near, torch.arange(n, device=dist.device), torch.full_like(cluster, n))
-        pick = torch.full((m,), n, device=dist.device, dtype=torch.long).scatter_reduce(0, cluster, ids, "amin")
-        cfeat = level.cfeat[pick].contiguous()
-        nb = level.offset.shape[0]
-        offset = _offsets(coords[:, 0], nb)
+        coords, new_stride, cfeat, offset, _, _, m = _pool_cells(level, self.stride)
         # LayerNorm and Linear act row by row, so they run once per source voxel instead of once per gathered copy
         y = self.linear(self.norm(level.feat))
         idx, _ = pointops.knn_query(self.k, level.xyz, level.offset, cfeat[:, 1:4].contiguous(), offset,
@@ -170,7 +236,7 @@ class GridKNNDownsample(nn.Module):
         else:
             starts = torch.arange(0, (m + 1) * self.k, self.k, device=idx.device, dtype=torch.int32)
             feat = ops.pool_max(y, idx.reshape(-1).contiguous(), starts, m)
-        return _Level(coords.int().contiguous(), new_stride, feat, cfeat, offset)
+        return _Level(coords, new_stride, feat, cfeat, offset)
 
 
 class BasicLayer(WindowStage):
@@ -222,18 +288,22 @@ class Swin3DUNet(nn.Module):
                  drop_path_rate=0.2, up_k=3, num_layers=5, stem_transformer=True, down_stride=2, upsample="linear",
                  knn_down=True, cRSE="XYZ_RGB", fp16_mode=0):
         super().__init__()
-        if not knn_down:
-            raise NotImplementedError("Swin3D-v1m1: knn_down=False (GridDownsample) is not built")
-        if not stem_transformer:
-            raise NotImplementedError("Swin3D-v1m1: stem_transformer=False (MinkResBlock stem) is not built")
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        downsample = GridKNNDownsample if knn_down else GridDownsample
         self.cRSE = cRSE
-        self.stem_layer = _ConvBNRelu(in_channels, channels[0], kernel_size=3, stride=1)
-        self.layer_start = 0
+        if stem_transformer:
+            self.stem_layer = _ConvBNRelu(in_channels, channels[0], kernel_size=3, stride=1)
+            self.layer_start = 0
+        else:
+            # :69-85: a residual stem, its own downsample, and no attention stage at the finest level
+            self.stem_layer = nn.Sequential(_ConvBNRelu(in_channels, channels[0], kernel_size=3, stride=1),
+                                            MinkResBlock(in_channels=channels[0], out_channels=channels[0]))
+            self.downsample = downsample(channels[0], channels[1], kernel_size=down_stride, stride=down_stride)
+            self.layer_start = 1
         self.layers = nn.ModuleList([
             BasicLayer(dim=channels[i], depth=depths[i], num_heads=num_heads[i], window_size=window_sizes[i],
                        quant_size=quant_size, drop_path=dpr[sum(depths[:i]):sum(depths[:i + 1])],
-                       downsample=GridKNNDownsample if i < num_layers - 1 else None,
+                       downsample=downsample if i < num_layers - 1 else None,
                        down_stride=down_stride if i == 0 else 2,
                        out_channels=channels[i + 1] if i < num_layers - 1 else None, cRSE=cRSE, fp16_mode=fp16_mode)
             for i in range(self.layer_start, num_layers)])
@@ -280,6 +350,9 @@ class Swin3DUNet(nn.Module):
         level, point2voxel = self.voxelize(data_dict)
         level = self.stem_layer(level)
         skips = []
+        if self.layer_start > 0:          # :213-216
+            skips.append(level)
+            level = self.downsample(level)
         for layer in self.layers:
             kept, level = layer(level)
             skips.append(kept)

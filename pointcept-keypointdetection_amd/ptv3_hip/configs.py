@@ -61,3 +61,7 @@ TINY_SWIN3D_CFG = dict(
     num_heads=[2, 2, 2], window_sizes=[5, 7, 7], quant_size=4, drop_path_rate=0.3, up_k=3, num_layers=3,
     stem_transformer=True, down_stride=3, upsample="linear_attn", knn_down=True, cRSE="XYZ_RGB_NORM", fp16_mode=1,
 )
+
+# the two constructor variants no shipped config uses: GridDownsample (knn_down=False) and the residual stem
+# (stem_transformer=False) - tests/golden/state_dict_swin3d_tiny_grid_resstem.txt lists the reference class built this way
+TINY_SWIN3D_GRID_RESSTEM_CFG = dict(TINY_SWIN3D_CFG, knn_down=False, stem_transformer=False)

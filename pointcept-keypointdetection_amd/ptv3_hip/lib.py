@@ -110,6 +110,7 @@ SIGNATURES = {
     "ptv3_keypoint_aggregate": (c_int, [P, P, P, c_int, c_int, P, P, c_int, c_float, P, P, P]),
     "ptv3_profile_enable": (c_int, [c_int]),
     "ptv3_profile_collect": (c_int, [P, P, P, P]),
+    "ptv3_profile_hint_flops": (c_int, [ctypes.c_double]),
     "ptv3_profile_kernel_count": (c_int, []),
     "ptv3_profile_kernel_name": (c_char_p, [c_int]),
     "ptv3_profile_collect_kernels": (c_int, [P, P, P, P]),

@@ -754,6 +754,9 @@ def swin_attention(q, k, v, q_table, k_table, v_table, table_offsets, n2n, w_sta
         raise ValueError("swin_attention: tables are shorter than sum(table_offsets)")
     out = torch.empty_like(q)
     offs = (ctypes.c_int32 * axes)(*[int(t) for t in table_offsets])
+    if _PROFILING:   # the pair count is device data: read back only while the launch is being bracketed
+        lens = (w_start[1:] - w_start[:-1]).double()
+        lib.ptv3_profile_hint_flops(float((lens * lens).sum().item()) * heads * (1 + 3 * axes) * 2 * hd)
     lib.check(lib.ptv3_swin_attn_fwd(_p(q), _p(k), _p(v), _p(q_table), _p(k_table), _p(v_table), offs, axes, _p(n2n),
                                      _p(w_start), w_start.shape[0] - 1, _p(n_crse), _p(out), n, heads, hd,
                                      int(max_tokens), _dt(q), _stream()), "ptv3_swin_attn_fwd")
@@ -898,7 +901,12 @@ def knn_query_cells(nsample, xyz, offset, new_xyz, new_offset, cell=None):
 FAMILIES = ("linear", "subm_conv", "window_attn", "backward")
 
 
+_PROFILING = False
+
+
 def profile_enable(on=True):
+    global _PROFILING
+    _PROFILING = bool(on)
     lib.check(lib.ptv3_profile_enable(int(on)), "ptv3_profile_enable")
 
 

@@ -4,9 +4,10 @@ tests/golden/state_dict_swin3d_s3dis.txt and state_dict_offset_swin3d.txt (key, 
 
 MinkowskiEngine and microsoft/Swin3D are not in the reference tree, so parameter-only stand-ins are installed for the
 import to succeed.  Keys that come from a stand-in rather than from reference code - and therefore pin nothing beyond
-MinkowskiEngine's documented parameter layout - are the stem's two modules:
+MinkowskiEngine's documented parameter layout - are the stem's modules:
     stem_layer.conv_layers.0.kernel          (kernel_size^3, in, out)   MinkowskiConvolution, bias=False
     stem_layer.conv_layers.1.bn.*            MinkowskiBatchNorm wraps torch.nn.BatchNorm1d as `.bn`
+    (third listing, stem_transformer=False: the same two kinds inside stem_layer.0 and MinkResBlock's conv1/2, norm1/2)
 Every other key (cRSE tables, qkv / proj / mlp, LayerNorms, downsample / upsample linears, classifier, head) is produced
 by the reference's own constructors.  No forward is run: the arithmetic of those libraries is not available.
 """
@@ -82,8 +83,15 @@ def main():
     importlib.import_module("pointcept.models.swin3d.swin3d_v1m1_base")
     importlib.import_module("pointcept.models.offset_keypoint_swin3d")
     from pointcept.models.builder import MODELS
+    # third listing: the two constructor variants no shipped config uses (GridDownsample, MinkResBlock stem) on the
+    # plumbing-size config of ptv3_hip/configs.py (TINY_SWIN3D_CFG)
+    tiny = dict(type="Swin3D-v1m1", in_channels=9, num_classes=13, base_grid_size=0.02, depths=[2, 2, 2],
+                channels=[16, 32, 32], num_heads=[2, 2, 2], window_sizes=[5, 7, 7], quant_size=4, drop_path_rate=0.3,
+                up_k=3, num_layers=3, stem_transformer=False, down_stride=3, upsample="linear_attn", knn_down=False,
+                cRSE="XYZ_RGB_NORM", fp16_mode=1)
     jobs = (("state_dict_swin3d_s3dis.txt", _cfg("configs/s3dis/semseg-swin3d-v1m1-0-small.py")["backbone"]),
-            ("state_dict_offset_swin3d.txt", _cfg("configs/my_dataset/offset_keypoint_swin3d.py")))
+            ("state_dict_offset_swin3d.txt", _cfg("configs/my_dataset/offset_keypoint_swin3d.py")),
+            ("state_dict_swin3d_tiny_grid_resstem.txt", tiny))
     for fname, cfg in jobs:
         model = MODELS.build(dict(cfg))
         with open(os.path.join(HERE, fname), "w") as f:

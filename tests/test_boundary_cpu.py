@@ -175,7 +175,8 @@ def test_models_register_with_the_reference_registry_and_build_from_its_config()
 
 
 @pytest.mark.parametrize("cfg_name,listing", [("SWIN3D_S3DIS_CFG", "state_dict_swin3d_s3dis.txt"),
-                                              ("OFFSET_SWIN3D_CFG", "state_dict_offset_swin3d.txt")])
+                                              ("OFFSET_SWIN3D_CFG", "state_dict_offset_swin3d.txt"),
+                                              ("TINY_SWIN3D_GRID_RESSTEM_CFG", "state_dict_swin3d_tiny_grid_resstem.txt")])
 def test_swin3d_state_dict_matches_the_reference_classes(cfg_name, listing):
     """Keys, shapes, dtypes and order of "Swin3D-v1m1" / "OffsetKeypointSwin3D" against listings taken from the
     reference's own constructors (tests/golden/make_golden_swin3d.py; its header names the two stem modules whose keys
@@ -192,10 +193,8 @@ def test_swin3d_state_dict_matches_the_reference_classes(cfg_name, listing):
 def test_swin3d_refuses_what_it_does_not_build():
     from ptv3_hip import configs
     from pointcept.models import build_model
-    with pytest.raises(NotImplementedError, match="knn_down=False"):
-        build_model(dict(configs.TINY_SWIN3D_CFG, knn_down=False))
-    with pytest.raises(NotImplementedError, match="stem_transformer=False"):
-        build_model(dict(configs.TINY_SWIN3D_CFG, stem_transformer=False))
+    build_model(dict(configs.TINY_SWIN3D_CFG, knn_down=False))            # GridDownsample: built since round 3
+    build_model(dict(configs.TINY_SWIN3D_CFG, stem_transformer=False))    # MinkResBlock stem: built since round 3
     with pytest.raises(NotImplementedError, match="attn_drop"):
         from pointcept.models.swin3d import WindowAttention
         WindowAttention(32, 5, 4, 2, attn_drop=0.1)
