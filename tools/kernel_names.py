@@ -9,6 +9,9 @@ def label(name):
     if m:
         return "gemm_big_kernel<%s,%sch> %s" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(4),
                                                  "gather (sparse conv)" if m.group(5) == "1" else "dense")
+    m = re.search(r"conv_tile_kernelI(DF16b|f)Li(\d+)E", n)
+    if m:
+        return "conv_tile_kernel<%s,%sch> gather (sparse conv)" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2))
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELb([01])(?:ELi(\d))?", n)
     if m:
         pd = ",pd%s" % m.group(4) if m.group(4) and m.group(4) != "1" else ""
@@ -24,7 +27,8 @@ def label(name):
     if m:
         return "window_attn_full_kernel<rpe%s,qt%s>" % (m.group(1), m.group(2))
     for k in ("window_attn_full_kernel", "window_attn_kernel", "ht_neighbors_kernel", "ht_insert_kernel",
-              "radix_scatter_kernel", "radix_hist_kernel", "knn_query_kernel"):
+              "radix_scatter_kernel", "radix_hist_kernel", "knn_query_kernel", "swin_attn_bwd_kernel", "swin_attn_kernel",
+              "conv_tile_kernel"):
         if k in n:
             return k
     return n.split("(")[0].replace("void ", "").replace("ptv3::", "")[:48]
