@@ -168,6 +168,19 @@ int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int cin, int c
  *         f1 = LN(x; g0,b0) + shortcut;  qkv = LN(f1; g1,b1) @ wqkv^T + bqkv               (:319-324, :188)
  *   tail: f2 = attn @ wproj^T + bproj + f1;  out = f2 + fc2(GELU(fc1(LN(f2; g2,b2))))       (:219, :326-334) */
 int ptv3_block_fusable(int c, int hidden, int dtype, int64_t m);
+/* One linear layer on whole rows with its LayerNorm neighbours folded in (csrc/block_wide.hip, rows_linear_kernel):
+ *   out = act(prologue(x) @ w^T + bias) [+ res],   x (m, c), w (cout, c) natural layout, out / res (m, cout)
+ *   g0 == NULL, g1 == NULL : prologue = identity                                   (attn.proj + shortcut, :219)
+ *   g0 == NULL, g1 != NULL : prologue = LayerNorm(x; g1, b1)                       (norm2 -> fc1 -> GELU, :330-333)
+ *   g0 != NULL             : f1 = LayerNorm(x; g0, b0) + shortcut, stored to `f1`, then LayerNorm(f1; g1, b1)
+ *                            (cpe LayerNorm + shortcut -> norm1 -> qkv, :319-324, :188)
+ * Every row is read once, the weights stream through LDS (LDS-DMA ring); replaces ptv3_layernorm + ptv3_gemm for
+ * c in {128, 256, 512} (fp32: up to 256), cout a multiple of 64 | 32.  ptv3_rows_linear_capable tells whether a shape
+ * is served; WHEN to prefer it over the tiled GEMM (row count) is the caller's policy. */
+int ptv3_rows_linear_capable(int c, int cout, int dtype, int64_t m);
+int ptv3_rows_linear(const void* x, const void* shortcut, const float* g0, const float* b0, const float* g1,
+                     const float* b1, const void* w, const float* bias, int act, const void* res, void* f1, void* out,
+                     int64_t m, int c, int cout, float eps, int dtype, void* stream);
 int ptv3_block_head(const void* x, const float* slab, int splits, const float* conv_bias, const void* shortcut,
                     const float* g0, const float* b0, const float* g1, const float* b1, const void* wqkv,
                     const float* bqkv, void* f1, void* qkv, int64_t m, int c, float eps, int dtype, void* stream);

@@ -531,6 +531,209 @@ __global__ void __launch_bounds__(256, WGS) block_head_wide_kernel(HeadArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One linear layer on whole rows with its neighbours folded in (the same weight-streaming machinery): for widths the
+// fused halves above do not cover (C = 512: 12 C^2 weights per 128 rows would be 6.3 MB of stream) and for the
+// linears outside a block.
+//   out = act(prologue(x) @ w^T + bias) [+ res]
+//   prologue  PRO = 0: x as it is;  1: LayerNorm(x; g1, b1);
+//             2: f1 = LayerNorm(x; g0, b0) + shortcut (stored), then LayerNorm(f1; g1, b1)   (Block.forward :319-324)
+// A workgroup owns 64 RT rows and the output channels [y, y + 1) x cout / gridDim.y (column groups only for small m);
+// the rows are read ONCE (the tiled GEMM re-reads them per 64-channel column tile: 4x the algorithmic traffic on the
+// C = 512 level of a LiDAR scan), LayerNorm runs on the packed fragments (statistics by a second unpack, nothing
+// but the fragments stays live), units of HSLR weight rows x C stream through the LDS ring.
+// ------------------------------------------------------------------------------------------------------------
+// a 16-byte fragment the compiler may not see through (no instruction: keeps it from caching values derived from it)
+template <typename FR> __device__ __forceinline__ FR opaque16(FR f) {
+  u32x4 u = __builtin_bit_cast(u32x4, f);
+  asm volatile("" : "+v"(u));
+  return __builtin_bit_cast(FR, u);
+}
+
+struct RowsLinArgs {
+  const void* x; const void* shortcut;
+  const float *g0, *b0, *g1, *b1;
+  const void* w; const float* bias; const void* res;
+  void* f1; void* out;
+  int64_t m; int cout; int act; float eps;
+};
+
+template <typename T, int NT, int RT, int HSLR, int PRO>
+__global__ void __launch_bounds__(256) rows_linear_kernel(RowsLinArgs a) {
+  typedef Frag<T> F;
+  typedef typename F::type FR;
+  typedef Wide<T> W;
+  constexpr int C = 16 * NT, E = F::E, KC = F::KC, NKC = C / KC, NH = HSLR / 16;
+  constexpr int NP = C / W::PK;
+  constexpr int UB = HSLR * C * (int)sizeof(T);
+  constexpr int DPU = UB / 4096;
+  constexpr int NBUF = 3, AH = NBUF - 1;
+  static_assert(UB <= 32 * 1024 && UB % 4096 == 0, "unit size");
+  extern __shared__ __attribute__((aligned(16))) char wide_smem[];
+  char* ring = wide_smem;
+  float* sVec = reinterpret_cast<float*>(wide_smem + NBUF * UB);   // g0, b0, g1, b1 [C each], bias [cout]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  char* stage = reinterpret_cast<char*>(sVec + 4 * C + a.cout) + wave * wide_stage_bytes<RT>();
+  const T* w = reinterpret_cast<const T*>(a.w);
+  const int units = a.cout / HSLR;
+  const int upw = (units + gridDim.y - 1) / gridDim.y;
+  const int u0 = blockIdx.y * upw;
+  const int nu = min(units, u0 + upw) - u0;        // units of this workgroup (>= 1 by the launcher's split)
+
+  auto issue = [&](int u) {
+    char* buf = ring + (u % NBUF) * UB;
+    const T* src = w + (int64_t)(u0 + u) * HSLR * C;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dma_panel<T, HSLR, false>(buf + p * HSLR * 128, src + p * W::PK, C, wave, lane);
+  };
+  if constexpr (PRO == 2) { dma_floats(sVec, a.g0, C, wave, lane); dma_floats(sVec + C, a.b0, C, wave, lane); }
+  if constexpr (PRO >= 1) { dma_floats(sVec + 2 * C, a.g1, C, wave, lane); dma_floats(sVec + 3 * C, a.b1, C, wave, lane); }
+  dma_floats(sVec + 4 * C, a.bias, a.cout, wave, lane);
+#pragma unroll
+  for (int i = 0; i < AH; ++i)
+    if (i < nu) issue(i);
+  const float *vg0 = sVec, *vb0 = sVec + C, *vg1 = sVec + 2 * C, *vb1 = sVec + 3 * C, *vbias = sVec + 4 * C;
+
+  const int64_t base = ((int64_t)blockIdx.x * 4 + wave) * (16 * RT);
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const __amdgpu_buffer_rsrc_t ors = out_rsrc<T>(reinterpret_cast<T*>(a.out), a.m, a.cout);
+  // rows in NATURAL channel order: lane (i, g) holds channels KC kc + E g .. + E - 1 of row i
+  FR xf[RT][NKC];
+  int64_t rc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const int64_t row = base + 16 * t + li;
+    rc[t] = row < a.m ? row : a.m - 1;
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) xf[t][kc] = *reinterpret_cast<const FR*>(x + rc[t] * C + KC * kc + E * g);
+  }
+  // vectors + first unit visible.  (nu < AH leaves fewer copies in flight than the counted wait assumes: wait for all.)
+  if (nu >= AH) wide_sync<DPU, AH, 0>(0, nu); else wide_sync<DPU, 1, 0>(0, 1);
+  if (AH < nu) issue(AH);
+  if constexpr (PRO >= 1) {
+    // LayerNorm on the packed fragments: mean, then centred second moment (two unpacks), then normalise in place
+    auto stats = [&](const FR (&fr)[NKC], float& mean, float& rstd) {
+      float s = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        float v[E];
+        FragF<T>::unpack(fr[kc], v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s += v[e];
+      }
+      mean = groups_sum(s) * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        float v[E];
+        // (the fragment is made opaque first: otherwise the compiler keeps the floats of the first pass - C / 4 live
+        // registers per row tile, spilled at C = 512 - instead of unpacking again)
+        FragF<T>::unpack(opaque16(fr[kc]), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) { const float d = v[e] - mean; q += d * d; }
+      }
+      rstd = rsqrtf(groups_sum(q) * (1.0f / C) + a.eps);
+    };
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      float mean, rstd;
+      if constexpr (PRO == 2) {
+        const T* sc = reinterpret_cast<const T*>(a.shortcut);
+        const __amdgpu_buffer_rsrc_t f1rs = out_rsrc<T>(reinterpret_cast<T*>(a.f1), a.m, C);
+        FR sr[NKC];
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) sr[kc] = *reinterpret_cast<const FR*>(sc + rc[t] * C + KC * kc + E * g);
+        stats(xf[t], mean, rstd);
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+          float v[E], sh[E];
+          FragF<T>::unpack(opaque16(xf[t][kc]), v);
+          FragF<T>::unpack(sr[kc], sh);
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int ch = KC * kc + E * g + e;
+            v[e] = (v[e] - mean) * rstd * vg0[ch] + vb0[ch] + sh[e];
+          }
+          xf[t][kc] = FragF<T>::pack(v);      // rounded to T: f1 as stored, and what LayerNorm_1 sees
+          if (blockIdx.y == 0) store16<T>(f1rs, base + 16 * t + li, C, KC * kc + E * g, xf[t][kc]);
+          // one K chunk at a time: hoisting every chunk's vector reads ahead costs 2 C / 4 registers per row tile
+          if constexpr (C >= 512) __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      stats(xf[t], mean, rstd);
+#pragma unroll
+      for (int kc = 0; kc < NKC; ++kc) {
+        float v[E];
+        FragF<T>::unpack(opaque16(xf[t][kc]), v);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int ch = KC * kc + E * g + e;
+          v[e] = (v[e] - mean) * rstd * vg1[ch] + vb1[ch];
+        }
+        xf[t][kc] = FragF<T>::pack(v);
+        if constexpr (C >= 512) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  const T* res = reinterpret_cast<const T*>(a.res);
+  for (int u = 0; u < nu; ++u) {
+    if (u > 0) {
+      // stricter than needed while output (and f1) stores are in flight: their count varies with PRO and the split
+      wide_sync<DPU, AH, 0>(u, nu);
+      if (u + AH < nu) issue(u + AH);
+    }
+    const char* buf = ring + (u % NBUF) * UB;
+    f32x4 acc[RT][NH];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int jj = 0; jj < NH; ++jj) acc[t][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unit_gemm<T, RT, NH, NKC, true>(buf, HSLR, xf, acc, 0, li, g);
+    const int col0 = (u0 + u) * HSLR;
+#pragma unroll
+    for (int jj = 0; jj < NH; ++jj) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(vbias + col0 + 16 * jj + 4 * g);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        if (a.act == PTV3_ACT_GELU) gelu_bias4<T>(acc[t][jj], b);
+        else if (a.act == PTV3_ACT_RELU) { acc[t][jj] += b; for (int r = 0; r < 4; ++r) acc[t][jj][r] = fmaxf(acc[t][jj][r], 0.f); }
+        else acc[t][jj] += b;
+      }
+    }
+    // staged tile -> whole 128-byte row pieces (HSLR = 32 bf16 channels: 64-byte pieces), residual added on the way out
+    {
+      typedef typename Vec4<T>::type V4;
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int jj = 0; jj < NH; ++jj)
+          *reinterpret_cast<V4*>(stage + (16 * t + li) * WIDE_STAGE_ROW + (16 * jj + 4 * g) * (int)sizeof(T)) =
+              pack4<T>(acc[t][jj][0], acc[t][jj][1], acc[t][jj][2], acc[t][jj][3]);
+      constexpr int CPR = HSLR * (int)sizeof(T) / 16;      // 16-byte pieces per row of the tile (8 | 4)
+      constexpr int RPI = 64 / CPR;                         // rows per store instruction
+      const int rr = lane / CPR, cc = lane % CPR;
+#pragma unroll
+      for (int it = 0; it < 16 * RT / RPI; ++it) {
+        const int r = RPI * it + rr;
+        FR piece = *reinterpret_cast<const FR*>(stage + r * WIDE_STAGE_ROW + 16 * cc);
+        const int64_t row = base + r;
+        if (res) {
+          const int64_t rrow = row < a.m ? row : a.m - 1;
+          const FR rp = *reinterpret_cast<const FR*>(res + rrow * a.cout + col0 + cc * E);
+          float v[E], rv[E];
+          FragF<T>::unpack(piece, v);
+          FragF<T>::unpack(rp, rv);
+#pragma unroll
+          for (int e = 0; e < E; ++e) v[e] += rv[e];
+          piece = FragF<T>::pack(v);
+        }
+        store16<T>(ors, row, a.cout, col0 + cc * E, piece);
+      }
+    }
+  }
+}
+
 template <typename T, int RT, int NBUF> static size_t wide_tail_lds(int c, int hidden) {
   return (size_t)NBUF * 128 * c + (size_t)(4 * c + hidden) * sizeof(float) + 4 * wide_stage_bytes<RT>();
 }
@@ -614,4 +817,79 @@ void launch_block_tail_wide(const TailArgs& a0, int c, int dtype, hipStream_t s)
   }
 }
 
+// ---- ptv3_rows_linear: capability and launch
+static int rows_hslr(int c, int dtype) {
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  int h = 64;
+  while (h > 16 && h * c * esz > 32 * 1024) h >>= 1;
+  return h;
+}
+bool rows_linear_capable(int c, int cout, int dtype, int64_t m) {
+  if (!(c == 128 || c == 256 || c == 512) || (dtype != PTV3_F32 && dtype != PTV3_BF16)) return false;
+  const int h = rows_hslr(c, dtype);
+  if (h < 32 || cout % h != 0 || cout > 8192) return false;     // fp32 at c = 512: a 32-row unit would be 64 KB
+  return m * (int64_t)std::max(cout, c) * (dtype == PTV3_F32 ? 4 : 2) < ((int64_t)1 << 31) - (1 << 20);
+}
+
+template <typename T, int NT, int RT, int HSLR, int PRO>
+static void launch_rows_pro(const RowsLinArgs& a, hipStream_t s) {
+  const int c = 16 * NT;
+  const size_t lds = (size_t)3 * HSLR * c * sizeof(T) + (size_t)(4 * c + a.cout) * sizeof(float) + 4 * wide_stage_bytes<RT>();
+  const int64_t tiles = cdiv(a.m, 64 * RT);
+  const int units = a.cout / HSLR;
+  // column groups only when the row tiles alone leave CUs idle (every group re-reads and re-normalises the rows)
+  const int split = tiles >= 192 ? 1 : (int)std::min<int64_t>(units, cdiv(256, tiles));
+  ensure_dynamic_lds(reinterpret_cast<const void*>(&rows_linear_kernel<T, NT, RT, HSLR, PRO>), 160 * 1024);
+  hipLaunchKernelGGL((rows_linear_kernel<T, NT, RT, HSLR, PRO>), dim3((unsigned)tiles, (unsigned)split), dim3(256), lds, s, a);
+}
+
+// RT: two 16-row tiles per wave halve the weight stream per row; at C = 512 the LayerNorm prologues of two tiles do not
+// fit the register file next to the 128 fragment registers (the compiler spills ~1 KB per lane): one tile there
+template <typename T, int NT, int RT, int HSLR>
+static void launch_rows(const RowsLinArgs& a, int pro, hipStream_t s) {
+  constexpr int RTP = (NT >= 32) ? 1 : RT;
+  if (pro == 2) launch_rows_pro<T, NT, RTP, HSLR, 2>(a, s);
+  else if (pro == 1) launch_rows_pro<T, NT, RTP, HSLR, 1>(a, s);
+  else launch_rows_pro<T, NT, RT, HSLR, 0>(a, s);
+}
+
+void launch_rows_linear(const RowsLinArgs& a, int c, int pro, int dtype, hipStream_t s) {
+  if (dtype == PTV3_F32) {
+    if (c == 128) launch_rows<float, 8, 1, 32>(a, pro, s); else launch_rows<float, 16, 1, 32>(a, pro, s);
+  } else {
+    if (c == 128) launch_rows<__bf16, 8, 2, 64>(a, pro, s);
+    else if (c == 256) launch_rows<__bf16, 16, 2, 64>(a, pro, s);
+    else launch_rows<__bf16, 32, 2, 32>(a, pro, s);
+  }
+}
+
 }  // namespace ptv3
+
+using namespace ptv3;
+
+extern "C" int ptv3_rows_linear_capable(int c, int cout, int dtype, int64_t m) {
+  return rows_linear_capable(c, cout, dtype, m) ? 1 : 0;
+}
+
+extern "C" int ptv3_rows_linear(const void* x, const void* shortcut, const float* g0, const float* b0, const float* g1,
+                                const float* b1, const void* w, const float* bias, int act, const void* res, void* f1,
+                                void* out, int64_t m, int c, int cout, float eps, int dtype, void* stream) {
+  PTV3_REQUIRE(rows_linear_capable(c, cout, dtype, m), "rows_linear: c=%d cout=%d dtype=%d m=%lld not served", c, cout,
+               dtype, (long long)m);
+  PTV3_REQUIRE(x && w && bias && out, "rows_linear: x, w, bias and out are required");
+  PTV3_REQUIRE((g1 == nullptr) == (b1 == nullptr) && (g0 == nullptr) == (b0 == nullptr), "rows_linear: LayerNorm weight and bias come together");
+  const int pro = g0 ? 2 : (g1 ? 1 : 0);
+  PTV3_REQUIRE(pro != 2 || (g1 && shortcut && f1), "rows_linear: the chained prologue needs g1/b1, shortcut and f1");
+  if (m == 0) return PTV3_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const RowsLinArgs a{x, shortcut, g0, b0, g1, b1, w, bias, res, f1, out, m, cout, act, eps};
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_LINEAR, 2.0 * m * c * (double)cout,
+                              ((double)m * c * (1 + 2 * (pro == 2)) + (double)c * cout + (double)m * cout * (1 + (res != nullptr))) * esz,
+                              nullptr, 0, 0.0);
+  prof_kernel(prof, PK_ROWS_LINEAR);
+  launch_rows_linear(a, c, pro, dtype, s);
+  prof_end(prof, s);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}

@@ -223,6 +223,14 @@ struct Run {
     F->off = mark;  // stream order makes immediate reuse safe
   }
 
+  // whole-row linears (ptv3_rows_linear) instead of LayerNorm + tiled GEMM launches: measured ahead at 245 .. 1388 rows
+  // (column groups) and at 27 743+ rows alike (tools/bench_block_wide.py); PTV3_ROWS_MIN raises the row count it starts at
+  bool rows_path(int64_t n, int C, int hidden) const {
+    static const int64_t min_rows = [] { const char* e = getenv("PTV3_ROWS_MIN"); return e ? atoll(e) : (int64_t)0; }();
+    return n >= min_rows && ptv3_rows_linear_capable(C, 3 * C, d->dtype, n) && ptv3_rows_linear_capable(C, C, d->dtype, n) &&
+           ptv3_rows_linear_capable(C, hidden, d->dtype, n);
+  }
+
   int patch_K(const Level& L, int patch) const {
     if (d->enable_flash) return patch;
     int64_t mn = L.off_host[0];
@@ -332,6 +340,8 @@ struct Run {
       void* qkv = F->alloc(row * 3 * C); void* t4 = F->alloc(row * C); void* f2 = F->alloc(row * C);
       void* t5 = F->alloc(row * C); void* t6 = F->alloc(row * hidden);
       const int splits = ptv3_gemm_splits(L.n, C, C, 27, d->dtype);
+      // whole-row linears with their LayerNorms folded in (ptv3_rows_linear): every row read once, no LayerNorm launch
+      const bool rows = rows_path(L.n, C, hidden);
       if (splits > 1) {
         // the conv leaves its split-K slabs; the LayerNorm kernel sums them (no separate reduce launch)
         const size_t wsb = ptv3_gemm_workspace_bytes(L.n, C, C, 27, d->dtype);
@@ -340,15 +350,27 @@ struct Run {
                       nullptr, nullptr, nullptr, d->dtype, slab, wsb, sf));
         RUN(ptv3_layernorm_slabs(slab, splits, conv_b, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps,
                                  d->dtype, sf));
+        gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+      } else if (rows) {
+        gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+        RUN(ptv3_rows_linear(t2, L.feat, ln0_g, ln0_b, n1_g, n1_b, qkv_w, qkv_b, 0, nullptr, f1, qkv, L.n, C, 3 * C,
+                             d->ln_eps, d->dtype, sf));
       } else {
         gemm(L.conv_feat, conv_w, t2, L.n, C, C, 27, L.nbr3, L.row_order, conv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
         RUN(ptv3_layernorm(t2, ln0_g, ln0_b, L.feat, f1, n1_g, n1_b, t3, L.n, C, d->ln_eps, d->dtype, sf));
+        gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
       }
-      gemm(t3, qkv_w, qkv, L.n, C, 3 * C, 1, nullptr, nullptr, qkv_b, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
       attention(L, P, qkv, t4, C, H, oi, scale);
-      gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
-      RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, sf));
-      gemm(t5, fc1_w, t6, L.n, C, hidden, 1, nullptr, nullptr, fc1_b, nullptr, nullptr, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
+      if (rows) {
+        RUN(ptv3_rows_linear(t4, nullptr, nullptr, nullptr, nullptr, nullptr, proj_w, proj_b, 0, f1, nullptr, f2, L.n, C, C,
+                             d->ln_eps, d->dtype, sf));
+        RUN(ptv3_rows_linear(f2, nullptr, nullptr, nullptr, n2_g, n2_b, fc1_w, fc1_b, PTV3_ACT_GELU, nullptr, nullptr, t6,
+                             L.n, C, hidden, d->ln_eps, d->dtype, sf));
+      } else {
+        gemm(t4, proj_w, f2, L.n, C, C, 1, nullptr, nullptr, proj_b, nullptr, nullptr, 0, f1, nullptr, nullptr);
+        RUN(ptv3_layernorm(f2, n2_g, n2_b, nullptr, t5, nullptr, nullptr, nullptr, L.n, C, d->ln_eps, d->dtype, sf));
+        gemm(t5, fc1_w, t6, L.n, C, hidden, 1, nullptr, nullptr, fc1_b, nullptr, nullptr, PTV3_ACT_GELU, nullptr, nullptr, nullptr);
+      }
       gemm(t6, fc2_w, L.feat, L.n, hidden, C, 1, nullptr, nullptr, fc2_b, nullptr, nullptr, 0, f2, nullptr, nullptr);
     }
     L.conv_feat = L.feat;

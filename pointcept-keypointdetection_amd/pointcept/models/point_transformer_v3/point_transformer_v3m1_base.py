@@ -233,6 +233,15 @@ class Block(PointModule):
                 and isinstance(self.norm2[0], LayerNorm) and isinstance(self.cpe[0], SubMConv3d)
                 and isinstance(self.cpe[1], Linear))
 
+    def _rows_path(self, feat):
+        """the executor's rule (csrc/engine.hip Run::rows_path): every linear of the block served by ptv3_rows_linear and
+        enough rows for its grid of 64 | 128-row workgroups"""
+        mlp = self.mlp[0]
+        n, c = feat.shape
+        return (n >= ops.rows_linear_rows() and isinstance(mlp.act, nn.GELU) and self.attn.qkv.bias is not None
+                and self.cpe[2].eps == self.norm1[0].eps == self.norm2[0].eps
+                and all(ops.rows_linear_capable(c, co, feat.dtype, n) for co in (3 * c, c, mlp.fc1.out_features)))
+
     def folded_cpe(self, dtype):
         """xCPE conv followed by its Linear (:277-285) has no nonlinearity in between, so the Linear is folded
         into the 27 kernel taps once per weight version:  W'_d = W_lin @ W_d,  b' = W_lin @ b_conv + b_lin.
@@ -356,17 +365,32 @@ class Block(PointModule):
         g1, b1 = self.cpe[2].affine_f32()
         g2, b2 = self.norm1[0].affine_f32()
         slabs = ops.conv_slabs(spt.features, wf, nbr, 27, spt.row_order)
+        # whole-row linears with their LayerNorms folded in (ptv3_rows_linear; the executor takes the same branches)
+        rows = self._rows_path(point.feat)
+        dt = spt.features.dtype
         if slabs is not None:   # deep levels: the conv splits over K; the LayerNorm kernel sums the slabs
             feat, x = ops.layernorm_slabs(slabs[0], slabs[1], nbr.shape[0], wf.shape[0], bf, spt.features.dtype, g1, b1,
                                           self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)
+            qkv = self.attn.qkv(x)
+        elif rows:
+            x = ops.gemm(spt.features, wf, bias=bf, nbr=nbr, kvol=27, row_order=spt.row_order)
+            feat, qkv = ops.rows_linear(x, self.attn.qkv.weight_for(dt), self.attn.qkv.bias_f32(), ln=(g2, b2), ln0=(g1, b1),
+                                        shortcut=shortcut, eps=self.cpe[2].eps)
         else:
             x = ops.gemm(spt.features, wf, bias=bf, nbr=nbr, kvol=27, row_order=spt.row_order)
             feat, x = ops.layernorm(x, g1, b1, self.cpe[2].eps, res=shortcut, gamma2=g2, beta2=b2)
-        qkv = self.attn.qkv(x)
+            qkv = self.attn.qkv(x)
         x = self.attn.attention_core(point, qkv)
-        feat = self.attn.proj(x, res=feat)                  # + shortcut
-        x = self.norm2[0](feat)
-        feat = self.mlp[0](x, res=feat)                     # fc1+GELU, fc2 + shortcut
+        if rows:
+            feat = ops.rows_linear(x, self.attn.proj.weight_for(dt), self.attn.proj.bias_f32(), res=feat)
+            g3, b3 = self.norm2[0].affine_f32()
+            h = ops.rows_linear(feat, mlp.fc1.weight_for(dt), mlp.fc1.bias_f32(), act=ops.ACT_GELU, ln=(g3, b3),
+                                eps=self.norm2[0].eps)
+            feat = mlp.fc2(h, res=feat)
+        else:
+            feat = self.attn.proj(x, res=feat)                  # + shortcut
+            x = self.norm2[0](feat)
+            feat = self.mlp[0](x, res=feat)                     # fc1+GELU, fc2 + shortcut
         point.feat = feat
         point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(feat)
         return point

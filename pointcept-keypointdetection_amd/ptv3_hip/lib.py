@@ -58,6 +58,8 @@ SIGNATURES = {
                           P]),
     "ptv3_gemm_splits": (c_int, [c_int64, c_int, c_int, c_int, c_int]),
     "ptv3_block_fusable": (c_int, [c_int, c_int, c_int, c_int64]),
+    "ptv3_rows_linear_capable": (c_int, [c_int, c_int, c_int, c_int64]),
+    "ptv3_rows_linear": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int, c_float, c_int, P]),
     "ptv3_block_head": (c_int, [P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_float, c_int, P]),
     "ptv3_block_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int, c_int, c_float, c_int, P]),
     "ptv3_mlp2_fusable": (c_int, [c_int, c_int, c_int, c_int]),

@@ -297,6 +297,32 @@ def conv_slabs(x, w, nbr, kvol, row_order=None):
     return ws, splits
 
 
+def rows_linear_rows():
+    """row count from which the callers prefer ptv3_rows_linear to LayerNorm + tiled GEMM launches (PTV3_ROWS_MIN)"""
+    import os
+    return int(os.environ.get("PTV3_ROWS_MIN", "0"))
+
+
+def rows_linear_capable(c, cout, dtype, m):
+    return bool(lib.ptv3_rows_linear_capable(int(c), int(cout), _DT[dtype], int(m)))
+
+
+def rows_linear(x, w, bias, act=ACT_NONE, res=None, ln=None, ln0=None, shortcut=None, eps=1e-5):
+    """out = act(prologue(x) @ w^T + bias) [+ res] (see ptv3_rows_linear).  ln = (gamma, beta) of the LayerNorm in front
+    of the GEMM; ln0 = (gamma, beta) + `shortcut`: f1 = LayerNorm(x; ln0) + shortcut first -> returns (f1, out)."""
+    _chk(x, "x", (torch.float32, torch.bfloat16), 2)
+    _chk(w, "w", x.dtype, 2)
+    m, c = x.shape
+    cout = w.shape[0]
+    out = torch.empty((m, cout), dtype=x.dtype, device=x.device)
+    f1 = torch.empty_like(x) if ln0 is not None else None
+    g0, b0 = ln0 if ln0 is not None else (None, None)
+    g1, b1 = ln if ln is not None else (None, None)
+    lib.check(lib.ptv3_rows_linear(_p(x), _p(shortcut), _p(g0), _p(b0), _p(g1), _p(b1), _p(w), _p(bias), int(act), _p(res),
+                                   _p(f1), _p(out), m, c, cout, float(eps), _dt(x), _stream()), "ptv3_rows_linear")
+    return (f1, out) if ln0 is not None else out
+
+
 def block_head(x, slab, splits, conv_bias, shortcut, g0, b0, g1, b1, wqkv, bqkv, eps):
     """f1, qkv of the fused head (see ptv3_block_head)."""
     _chk(shortcut, "shortcut", (torch.float32, torch.bfloat16), 2)

@@ -379,6 +379,46 @@ def test_wide_block_halves_vs_torch(dev, c, m):
                 assert (got.float() - ref.float()).abs().max().item() <= 4 * 2.0 ** -8 * max(1.0, ref.float().abs().max().item())
 
 
+@pytest.mark.parametrize("c,m", [(128, 300), (256, 1388), (512, 245), (512, 20000 + 77), (256, 9000 + 3), (128, 1)])
+def test_rows_linear_vs_torch(dev, c, m):
+    """ptv3_rows_linear (csrc/block_wide.hip): the three prologues - none (proj + residual), LayerNorm (norm2 -> fc1 ->
+    GELU), LayerNorm + shortcut -> stored f1 -> LayerNorm (cpe norm + shortcut -> norm1 -> qkv) - against torch fp32 and,
+    in bf16, against the launches they replace.  Small m runs column groups (several workgroups per row tile), the
+    large cases end in a ragged row tile; c = 512 is served in bf16 only (fp32 keeps LayerNorm + tiled GEMM)."""
+    from ptv3_hip import ops
+    F = torch.nn.functional
+    g = torch.Generator().manual_seed(c + m)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    x, shortcut, res = rnd(m, c) * 1.5 + 0.3, rnd(m, c), rnd(m, c)
+    g0, b0, g1, b1 = rnd(c), rnd(c), rnd(c), rnd(c)
+    wqkv, bqkv = rnd(3 * c, c) / c ** 0.5, rnd(3 * c)
+    wproj, bproj = rnd(c, c) / c ** 0.5, rnd(c)
+    w1, bias1 = rnd(4 * c, c) / c ** 0.5, rnd(4 * c)
+    f1_ref = F.layer_norm(x, (c,), g0, b0, 1e-5) + shortcut
+    qkv_ref = F.linear(F.layer_norm(f1_ref, (c,), g1, b1, 1e-5), wqkv, bqkv)
+    proj_ref = F.linear(x, wproj, bproj) + res
+    fc1_ref = F.gelu(F.linear(F.layer_norm(x, (c,), g1, b1, 1e-5), w1, bias1))
+    d = lambda t: t.to(dev).contiguous()  # noqa: E731
+    for dtype in (torch.float32, torch.bfloat16):
+        if not ops.rows_linear_capable(c, 3 * c, dtype, m):
+            assert (c, dtype) == (512, torch.float32)
+            continue
+        cv = lambda t: d(t).to(dtype).contiguous()  # noqa: E731
+        f1, qkv = ops.rows_linear(cv(x), cv(wqkv), d(bqkv), ln=(d(g1), d(b1)), ln0=(d(g0), d(b0)), shortcut=cv(shortcut))
+        proj = ops.rows_linear(cv(x), cv(wproj), d(bproj), res=cv(res))
+        fc1 = ops.rows_linear(cv(x), cv(w1), d(bias1), act=ops.ACT_GELU, ln=(d(g1), d(b1)))
+        for got, ref in ((f1, f1_ref), (qkv, qkv_ref), (proj, proj_ref), (fc1, fc1_ref)):
+            tol = FP32_TOL if dtype == torch.float32 else 8 * 2.0 ** -8
+            assert (got.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+        if dtype == torch.bfloat16:
+            f1u, t3 = ops.layernorm(cv(x), d(g0), d(b0), 1e-5, res=cv(shortcut), gamma2=d(g1), beta2=d(b1))
+            pairs = ((f1, f1u), (qkv, ops.gemm(t3, cv(wqkv), bias=d(bqkv))),
+                     (proj, ops.gemm(cv(x), cv(wproj), bias=d(bproj), res=cv(res))),
+                     (fc1, ops.gemm(ops.layernorm(cv(x), d(g1), d(b1), 1e-5), cv(w1), bias=d(bias1), act=ops.ACT_GELU)))
+            for got, ref in pairs:   # a few bf16 steps of the value (summation order; the polynomial GELU of the bf16 path)
+                assert (got.float() - ref.float()).abs().max().item() <= 4 * 2.0 ** -8 * max(1.0, ref.float().abs().max().item())
+
+
 # ------------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------------

@@ -86,5 +86,24 @@ def main():
         print(f"C={c:<4d}M={m:<8d}      {th:10.1f}{tu:10.1f}{tt:10.1f}{tv:17.1f}   tail {fl_t / tt / 1e6:6.0f} TFLOP/s", flush=True)
 
 
+def rows_bench():
+    """ptv3_rows_linear on the C = 512 level of the LiDAR scan (27 743 rows) against LayerNorm + tiled GEMM launches"""
+    print(f"{'rows_linear':24s}{'LN0+LN1+qkv':>12s}{'unfused':>9s}{'proj+res':>10s}{'unfused':>9s}{'LN+fc1+GELU':>13s}{'unfused':>9s}   (us, bf16)")
+    for c, m in ((512, 27743), (256, 56504), (128, 80168), (256, 1388), (512, 245)):
+        p = make(c, m, 2)
+        q = {k: (v.to(dev).bfloat16() if v.dim() == 2 else v.to(dev)).contiguous() for k, v in p.items()}
+        t = [timeit(lambda: ops.rows_linear(q["x"], q["wqkv"], q["bqkv"], ln=(q["g1"], q["b1"]), ln0=(q["g0"], q["b0"]), shortcut=q["shortcut"])),
+             timeit(lambda: unfused_head(q)),
+             timeit(lambda: ops.rows_linear(q["attn"], q["wproj"], q["bproj"], res=q["shortcut"])),
+             timeit(lambda: ops.gemm(q["attn"], q["wproj"], bias=q["bproj"], res=q["shortcut"])),
+             timeit(lambda: ops.rows_linear(q["x"], q["w1"], q["bias1"], act=ops.ACT_GELU, ln=(q["g2"], q["b2"]))),
+             timeit(lambda: ops.gemm(ops.layernorm(q["x"], q["g2"], q["b2"], 1e-5), q["w1"], bias=q["bias1"], act=ops.ACT_GELU))]
+        print(f"C={c:<4d}M={m:<8d}      " + "".join(f"{v:11.1f}" for v in t), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if os.environ.get("WIDE_ROWS_ONLY"):
+        rows_bench()
+    else:
+        main()
+        rows_bench()
