@@ -394,7 +394,10 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
 #pragma unroll
     for (int c = 0; c < ND; ++c) o[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const V4 ones = RowSum<T>::ones();
+  // the all-ones A operand of the row-sum product, made opaque once: as a known constant the compiler re-creates it
+  // from scalar registers (two v_mov_b64) in front of every use
+  V4 ones = RowSum<T>::ones();
+  asm volatile("" : "+v"(ones));
 
   auto tile_body = [&](const int tile, auto mask_tag) {
     constexpr bool MASK = decltype(mask_tag)::value;

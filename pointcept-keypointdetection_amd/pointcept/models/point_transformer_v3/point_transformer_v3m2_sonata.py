@@ -65,25 +65,21 @@ class Block(PointModule):
                                        out_channels=channels, act_layer=act_layer, drop=proj_drop))
         self.drop_path = PointSequential(DropPath(drop_path) if drop_path > 0.0 else nn.Identity())
 
+    def _residual_branch(self, point, norm, body, scale):
+        """One residual branch of the block in either norm placement (reference :343-360):
+        pre_norm:  x <- x + drop_path(scale(body(norm(x))));   post-norm:  x <- norm(x + drop_path(scale(body(x))))."""
+        skip = point.feat
+        branch_in = norm(point) if self.pre_norm else point
+        point = self.drop_path(scale(body(branch_in)))
+        point.feat = skip + point.feat
+        return point if self.pre_norm else norm(point)
+
     def forward(self, point: Point):
-        """Statement order of the reference (:338-362)."""
-        shortcut = point.feat
-        point = self.cpe(point)
-        point.feat = shortcut + point.feat
-        shortcut = point.feat
-        if self.pre_norm:
-            point = self.norm1(point)
-        point = self.drop_path(self.ls1(self.attn(point)))
-        point.feat = shortcut + point.feat
-        if not self.pre_norm:
-            point = self.norm1(point)
-        shortcut = point.feat
-        if self.pre_norm:
-            point = self.norm2(point)
-        point = self.drop_path(self.ls2(self.mlp(point)))
-        point.feat = shortcut + point.feat
-        if not self.pre_norm:
-            point = self.norm2(point)
+        skip = point.feat
+        point = self.cpe(point)                                 # xCPE: conv -> linear -> norm, added to its input (:339-341)
+        point.feat = skip + point.feat
+        point = self._residual_branch(point, self.norm1, self.attn, self.ls1)
+        point = self._residual_branch(point, self.norm2, self.mlp, self.ls2)
         point.sparse_conv_feat = point.sparse_conv_feat.replace_feature(point.feat)
         return point
 
@@ -171,24 +167,24 @@ class GridUnpooling(PointModule):
         self.traceable = traceable
 
     def forward(self, point):
-        assert "pooling_parent" in point.keys()
-        assert "pooling_inverse" in point.keys()
-        parent = point.pop("pooling_parent")
-        inverse = point.pooling_inverse
-        segments = point.get("_pool_segments")
-        feat = point.feat
-        parent = self.proj_skip(parent)
+        """reference :490-504: the coarse features, projected, are added to the projected skip features of the level
+        they were pooled from (row gather by `pooling_inverse`)."""
+        for key in ("pooling_parent", "pooling_inverse"):
+            assert key in point.keys(), f"GridUnpooling: point without {key}"
+        coarse_feat = point.feat                                # kept for traceable=True: proj() overwrites point.feat
+        fine = self.proj_skip(point.pop("pooling_parent"))
         up = self.proj(point).feat
+        segments = point.get("_pool_segments")
         if self.training and segments is not None:
-            gathered = A.cluster_gather(up, inverse, segments[0], segments[1])
+            carried = A.cluster_gather(up, point.pooling_inverse, segments[0], segments[1])
         else:
-            gathered = up[inverse]                      # row gather: index plumbing
-        parent.feat = parent.feat + gathered
-        parent.sparse_conv_feat = parent.sparse_conv_feat.replace_feature(parent.feat)
+            carried = up[point.pooling_inverse]                 # row gather: index plumbing
+        fine.feat = fine.feat + carried
+        fine.sparse_conv_feat = fine.sparse_conv_feat.replace_feature(fine.feat)
         if self.traceable:
-            point.feat = feat
-            parent["unpooling_parent"] = point
-        return parent
+            point.feat = coarse_feat
+            fine["unpooling_parent"] = point
+        return fine
 
 
 class Embedding(PointModule):
