@@ -140,7 +140,9 @@ int ptv3_subm_neighbors(const int32_t* indices, int64_t n, const void* table, in
  *   y2 = y + res[res_index ? res_index[i] : i][o]   (written to `out2` if given, else into `out`);
  * `out` always receives the pre-residual value when out2 != NULL.
  * row_order (optional, (m) int32): output tile t processes rows row_order[64t..] (locality only).
- * x: (rows_x, cin) dtype; out/out2/res: (m|rows, cout) dtype; w: dtype; bias/bn_*: fp32.
+ * x: (rows_x, cin) dtype - with nbr != NULL, rows_x = m: x is the feature matrix of the m active sites the table was
+ * built for (ptv3_subm_neighbors), which lets the kernels address it through a 32-bit buffer descriptor;
+ * out/out2/res: (m|rows, cout) dtype; w: dtype; bias/bn_*: fp32.
  * cin % 4 == 0 (fp32) / cin % 8 == 0 (bf16): 16-byte K granularity.
  * workspace (optional): ptv3_gemm_workspace_bytes(...) bytes of split-K slab room; shapes with few
  * rows and a long K (deep-stage convolutions) are then split over K and summed in slab order. */
@@ -505,10 +507,10 @@ int ptv3_keypoint_aggregate(const float* coord, const float* pred, const int64_t
                             int32_t* aux_out, void* stream);
 
 /* ---- measurement ---------------------------------------------------------------------------------
- * While enabled, ptv3_gemm and ptv3_window_attn_fwd bracket their launches with HIP events on the launch
- * stream.  collect() synchronises the device and returns, per kernel family (0 linear, 1 subm_conv,
- * 2 window_attn): summed device milliseconds, algorithmic flops (sparse conv: 2*cin*cout per ACTIVE
- * neighbour), algorithmic bytes and launch count since enable / the last collect. */
+ * While enabled, the GEMM / fused-block / attention entry points (forward and backward) bracket their launches with
+ * HIP events on the launch stream.  collect() synchronises the device and returns, per kernel family (0 linear,
+ * 1 subm_conv, 2 window_attn, 3 backward: arrays of FOUR entries): summed device milliseconds, algorithmic flops
+ * (sparse conv: 2*cin*cout per ACTIVE neighbour), algorithmic bytes and launch count since enable / the last collect. */
 int ptv3_profile_enable(int on);
 int ptv3_profile_collect(double* ms, double* flops, double* bytes, int64_t* launches);
 /* Flops of the NEXT bracketed launch, for kernels whose work is decided by device data the entry point does not read
