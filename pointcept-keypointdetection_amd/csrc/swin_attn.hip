@@ -22,6 +22,10 @@ constexpr int SWIN_MAX_AXES = 9;
 constexpr int SWIN_MAX_TOKENS = 512;   // w_w_id has 9 bits in the window key
 constexpr int SWIN_WAVES = 4;
 
+int swin_attn_mfma(int dtype, int D, int S, const void* q, const void* k, const void* v, const float* qt, const float* kt,
+                   const float* vt, const long long* start, const int* rows, const long long* n2n, const int* w_start,
+                   int nwin, const float* crse, void* out, int heads, int max_tokens, hipStream_t s);
+
 struct SwinTables {
   long long start[SWIN_MAX_AXES];   // element offset of axis c's slab inside each concatenated table
   int rows[SWIN_MAX_AXES];          // 2 L_c
@@ -285,8 +289,14 @@ extern "C" int ptv3_swin_attn_fwd(const void* q, const void* k, const void* v, c
   const int esz = dtype == PTV3_F32 ? 4 : 2;
   const int prof = prof_begin(s, PROF_WINDOW_ATTN, 0.0, 4.0 * (double)n * heads * head_dim * esz + 12.0 * n, nullptr, 0, 0.0);
   prof_kernel(prof, PK_SWIN_ATTN);
-  int rc;
-  if (dtype == PTV3_F32)
+  // table products on the matrix core (swin_attn_mfma.hip) unless switched off or the window does not fit its LDS plan
+  static const bool mfma_on = [] { const char* e = getenv("PTV3_SWIN_ATTN_MFMA"); return !(e && atoi(e) == 0); }();
+  int rc = -1;
+  if (mfma_on && at < (1ll << 31))
+    rc = swin_attn_mfma(dtype, head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab.start, tab.rows,
+                        (const long long*)n2n, w_start, num_windows, n_crse, out, heads, max_tokens, s);
+  if (rc != -1) {
+  } else if (dtype == PTV3_F32)
     rc = dispatch_dim<float>(head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab, (const long long*)n2n,
                              w_start, num_windows, n_crse, out, heads, max_tokens, s);
   else

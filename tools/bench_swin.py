@@ -121,7 +121,8 @@ def main():
         sig[:, 3:] = sig[:, 3:] * 2 - 1
         scale = torch.tensor([quant] * 3 + [quant * 2] * (nsig - 3), device=dev, dtype=torch.float32)
         cr = (sig * scale).contiguous()
-        run = lambda: ops.swin_attention(q, k, v, *tabs, offs, n2n, w_start, cr, ws ** 3)
+        mx = int(w_sizes.max().item())      # the model passes the largest window of the mapping (swin3d_layers.py:46)
+        run = lambda: ops.swin_attention(q, k, v, *tabs, offs, n2n, w_start, cr, mx)
         for _ in range(3):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
