@@ -10,7 +10,7 @@ enum { PROF_LINEAR = 0, PROF_SUBM_CONV = 1, PROF_WINDOW_ATTN = 2, PROF_BACKWARD 
 enum {
   PK_GEMM64_DENSE = 0, PK_GEMM64_CONV, PK_GEMM32_DENSE, PK_GEMM32_CONV, PK_GEMM_BIG_DENSE, PK_GEMM_BIG_CONV,
   PK_BLOCK_HEAD, PK_BLOCK_TAIL, PK_BLOCK_HEAD_COOP, PK_BLOCK_TAIL_COOP, PK_MLP2, PK_ATTN_FULL, PK_ATTN_TILED,
-  PK_BLOCK_HEAD_WIDE, PK_BLOCK_TAIL_WIDE, PK_CONV_TILE, PK_GEMM_TN, PK_ATTN_BWD_DQ, PK_ATTN_BWD_DKV, PK_SWIN_ATTN, PK_ROWS_LINEAR, PK_KERNELS
+  PK_BLOCK_HEAD_WIDE, PK_BLOCK_TAIL_WIDE, PK_CONV_TILE, PK_GEMM_TN, PK_ATTN_BWD_DQ, PK_ATTN_BWD_DKV, PK_SWIN_ATTN, PK_ROWS_LINEAR, PK_SWIN_ATTN_MFMA, PK_KERNELS
 };
 void prof_kernel(int rec, int kernel);   // tag the bracket opened by prof_begin (default: by family)
 bool prof_on();

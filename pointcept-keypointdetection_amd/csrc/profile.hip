@@ -13,7 +13,7 @@ static const char* const g_kernel_names[PK_KERNELS] = {
     "block_head_kernel", "block_tail_kernel", "block_head_coop_kernel", "block_tail_coop_kernel", "mlp2_kernel",
     "window_attn_full_kernel", "window_attn_kernel", "block_head_wide_kernel", "block_tail_wide_kernel",
     "conv_tile_kernel (sparse conv)", "gemm_tn_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
-    "swin_attn_kernel", "rows_linear_kernel"};
+    "swin_attn_kernel", "rows_linear_kernel", "swin_attn_mfma_kernel"};
 static bool g_on = false;
 static double g_hint_flops = -1.0;   // flops of the NEXT bracket, set by the caller that knows them (ptv3_profile_hint_flops)
 static std::vector<ProfRec> g_recs;

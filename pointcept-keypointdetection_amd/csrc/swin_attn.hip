@@ -290,12 +290,14 @@ extern "C" int ptv3_swin_attn_fwd(const void* q, const void* k, const void* v, c
   const int prof = prof_begin(s, PROF_WINDOW_ATTN, 0.0, 4.0 * (double)n * heads * head_dim * esz + 12.0 * n, nullptr, 0, 0.0);
   prof_kernel(prof, PK_SWIN_ATTN);
   // table products on the matrix core (swin_attn_mfma.hip) unless switched off or the window does not fit its LDS plan
-  static const bool mfma_on = [] { const char* e = getenv("PTV3_SWIN_ATTN_MFMA"); return !(e && atoi(e) == 0); }();
+  const char* mfma_env = getenv("PTV3_SWIN_ATTN_MFMA");      // read per call: tests run both kernels on the same inputs
+  const bool mfma_on = !(mfma_env && atoi(mfma_env) == 0);
   int rc = -1;
   if (mfma_on && at < (1ll << 31))
     rc = swin_attn_mfma(dtype, head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab.start, tab.rows,
                         (const long long*)n2n, w_start, num_windows, n_crse, out, heads, max_tokens, s);
   if (rc != -1) {
+    prof_kernel(prof, PK_SWIN_ATTN_MFMA);
   } else if (dtype == PTV3_F32)
     rc = dispatch_dim<float>(head_dim, num_axes, q, k, v, q_table, k_table, v_table, tab, (const long long*)n2n,
                              w_start, num_windows, n_crse, out, heads, max_tokens, s);

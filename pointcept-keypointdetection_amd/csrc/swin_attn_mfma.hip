@@ -33,23 +33,44 @@ struct SwinTablesM {
 // (A fence builtin would also drain vmcnt and with it the global loads issued ahead for the next tile.)
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
 
-// A / B fragment of 16 rows x 16 K of a row-major fp32 or bf16 matrix in global memory: lane (row = lane & 15, g) holds
-// elements d0 .. d0 + 3 of its row, zero past D
+// A / B fragment of 16 rows x 16 K of a row-major fp32 or bf16 matrix in global memory.  v_mfma_f32_16x16x4_f32 takes
+// K = 4 per step, one element per lane and step: with KE = min(D, 16) / 4 steps per chunk, lane (row = lane & 15, g)
+// holds elements 16 nc + KE g .. + KE - 1 of its row (head_dim 8: two steps instead of four half-empty ones).
 template <typename T, int D>
-__device__ __forceinline__ f32x4 row_frag(const T* __restrict__ row, int d0) {
-  if (d0 >= D) return f32x4{0.f, 0.f, 0.f, 0.f};
-  float t[4];
-  unpack4<T>(*reinterpret_cast<const typename Vec4<T>::type*>(row + d0), t);
-  return f32x4{t[0], t[1], t[2], t[3]};
+__device__ __forceinline__ f32x4 row_frag(const T* __restrict__ row, int nc, int g) {
+  constexpr int KE = D >= 16 ? 4 : D / 4;
+  const T* p = row + 16 * nc + KE * g;
+  if constexpr (KE == 4) {
+    float t[4];
+    unpack4<T>(*reinterpret_cast<const typename Vec4<T>::type*>(p), t);
+    return f32x4{t[0], t[1], t[2], t[3]};
+  } else {
+    static_assert(KE == 2, "head_dim 8, 16 or 32");
+    if constexpr (sizeof(T) == 4) {
+      const f32x2 t = *reinterpret_cast<const f32x2*>(p);
+      return f32x4{t[0], t[1], 0.f, 0.f};
+    } else {
+      const unsigned u = *reinterpret_cast<const unsigned*>(p);
+      return f32x4{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u), 0.f, 0.f};
+    }
+  }
 }
 
-// acc0 += A0 B, acc1 += A1 B over NCH chunks of 16 K: the two chains alternate, so neither waits for its own result
-template <int NCH>
-__device__ __forceinline__ void mma16_pair(const f32x4* a0, const f32x4* a1, const f32x4* b, f32x4& acc0, f32x4& acc1) {
+// acc += A B over NCH chunks of KE steps
+template <int NCH, int KE>
+__device__ __forceinline__ void mma_chain(const f32x4* a, const f32x4* b, f32x4& acc) {
 #pragma unroll
   for (int nc = 0; nc < NCH; ++nc)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
+    for (int e = 0; e < KE; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nc][e], b[nc][e], acc, 0, 0, 0);
+}
+// acc0 += A0 B, acc1 += A1 B: the two chains alternate, so neither waits for its own result
+template <int NCH, int KE>
+__device__ __forceinline__ void mma_chain_pair(const f32x4* a0, const f32x4* a1, const f32x4* b, f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+  for (int nc = 0; nc < NCH; ++nc)
+#pragma unroll
+    for (int e = 0; e < KE; ++e) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[nc][e], b[nc][e], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[nc][e], b[nc][e], acc1, 0, 0, 0);
     }
@@ -61,6 +82,7 @@ __global__ __launch_bounds__(64) void swin_attn_mfma_kernel(
     const float* __restrict__ kt, const float* __restrict__ vt, SwinTablesM tab, const long long* __restrict__ n2n,
     const int* __restrict__ w_start, const float* __restrict__ crse, T* __restrict__ out, int heads, int mt16, int TS, int nB, int ablate) {
   constexpr int NCH = (D + 15) / 16;       // 16-wide K chunks of the products over head_dim
+  constexpr int KE = D >= 16 ? 4 : D / 4;  // matrix-core steps per chunk
   constexpr int ND = (D + 15) / 16;        // 16-wide output column tiles
   constexpr int MAXCT = 4;                 // 16-row tiles of one axis' table (2 L_c <= 64)
   constexpr int VS = D + 4;                // row stride of the T_V slab copy
@@ -93,13 +115,14 @@ __global__ __launch_bounds__(64) void swin_attn_mfma_kernel(
     {
       const T* qrow = q + ((size_t)sRow[i0 + li] * heads + h) * D;
 #pragma unroll
-      for (int nc = 0; nc < NCH; ++nc) qf[nc] = row_frag<T, D>(qrow, 16 * nc + 4 * g);
+      for (int nc = 0; nc < NCH; ++nc) qf[nc] = row_frag<T, D>(qrow, nc, g);
     }
     for (int jt = 0; jt < mp; jt += 16) {
       const T* krow = k + ((size_t)sRow[jt + li] * heads + h) * D;
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 kf[NCH], acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int nc = 0; nc < NCH; ++nc) acc = mma16<float>(row_frag<T, D>(krow, 16 * nc + 4 * g), qf[nc], acc);
+      for (int nc = 0; nc < NCH; ++nc) kf[nc] = row_frag<T, D>(krow, nc, g);
+      mma_chain<NCH, KE>(kf, qf, acc);
       *reinterpret_cast<f32x4*>(sE + li * LP + jt + 4 * g) = acc;
     }
     // ---- table terms of the logits, one signal axis at a time
@@ -110,25 +133,28 @@ __global__ __launch_bounds__(64) void swin_attn_mfma_kernel(
       const float ci = sCT[c * mt16 + i0 + li];
       const size_t tbase = (size_t)tab.start[c] + hoff;
       f32x4 tq[MAXCT][NCH];
-      // table tiles in pairs: two independent accumulation chains interleave on the matrix core (a tile past the axis'
-      // rows repeats the last row; TS leaves room for it and nothing reads it)
+      // table tiles in pairs: two independent accumulation chains interleave on the matrix core
 #pragma unroll
       for (int ct = 0; ct < MAXCT; ct += 2) {
         if (ct < nct) {
+          const bool two = ct + 1 < nct;
           const size_t r0 = tbase + (size_t)min(16 * ct + li, rows - 1) * rstride;
           const size_t r1 = tbase + (size_t)min(16 * ct + 16 + li, rows - 1) * rstride;
           f32x4 tk0[NCH], tk1[NCH];
 #pragma unroll
           for (int nc = 0; nc < NCH; ++nc) {
-            tk0[nc] = row_frag<float, D>(kt + r0, 16 * nc + 4 * g);
-            tk1[nc] = row_frag<float, D>(kt + r1, 16 * nc + 4 * g);
-            tq[ct][nc] = row_frag<float, D>(qt + r0, 16 * nc + 4 * g);
-            tq[ct + 1][nc] = row_frag<float, D>(qt + r1, 16 * nc + 4 * g);
+            tk0[nc] = row_frag<float, D>(kt + r0, nc, g);
+            tq[ct][nc] = row_frag<float, D>(qt + r0, nc, g);
+            if (two) {
+              tk1[nc] = row_frag<float, D>(kt + r1, nc, g);
+              tq[ct + 1][nc] = row_frag<float, D>(qt + r1, nc, g);
+            }
           }
           f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-          mma16_pair<NCH>(tk0, tk1, qf, acc0, acc1);
+          if (two) mma_chain_pair<NCH, KE>(tk0, tk1, qf, acc0, acc1);
+          else mma_chain<NCH, KE>(tk0, qf, acc0);
           *reinterpret_cast<f32x4*>(sA + li * TS + 16 * ct + 4 * g) = acc0;        // QT_c[i = li][16 ct + 4 g ..]
-          *reinterpret_cast<f32x4*>(sA + li * TS + 16 * ct + 16 + 4 * g) = acc1;
+          if (two) *reinterpret_cast<f32x4*>(sA + li * TS + 16 * ct + 16 + 4 * g) = acc1;
         }
       }
       // KT_c of 16 keys at a time.  The products of tile jt + 16 are issued BEFORE the pairs of tile jt are looked up and
@@ -136,7 +162,7 @@ __global__ __launch_bounds__(64) void swin_attn_mfma_kernel(
       auto key_frags = [&](int jt, f32x4* kf) {
         const T* krow = k + ((size_t)sRow[jt + li] * heads + h) * D;
 #pragma unroll
-        for (int nc = 0; nc < NCH; ++nc) kf[nc] = row_frag<T, D>(krow, 16 * nc + 4 * g);
+        for (int nc = 0; nc < NCH; ++nc) kf[nc] = row_frag<T, D>(krow, nc, g);
       };
       f32x4 kacc[MAXCT];
       auto key_products = [&](const f32x4* kf) {
@@ -144,13 +170,14 @@ __global__ __launch_bounds__(64) void swin_attn_mfma_kernel(
         for (int ct = 0; ct < MAXCT; ct += 2) {
           kacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
           kacc[ct + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (ct < nct) mma16_pair<NCH>(tq[ct], tq[ct + 1], kf, kacc[ct], kacc[ct + 1]);
+          if (ct + 1 < nct) mma_chain_pair<NCH, KE>(tq[ct], tq[ct + 1], kf, kacc[ct], kacc[ct + 1]);
+          else if (ct < nct) mma_chain<NCH, KE>(tq[ct], kf, kacc[ct]);
         }
       };
       auto store_products = [&]() {
 #pragma unroll
         for (int ct = 0; ct < MAXCT; ++ct)
-          if (ct < ((nct + 1) & ~1)) *reinterpret_cast<f32x4*>(sB + li * TS + 16 * ct + 4 * g) = kacc[ct];   // KT_c[j = jt + li][16 ct + 4 g ..]
+          if (ct < nct) *reinterpret_cast<f32x4*>(sB + li * TS + 16 * ct + 4 * g) = kacc[ct];   // KT_c[j = jt + li][16 ct + 4 g ..]
       };
       f32x4 kf[NCH];
       key_frags(0, kf);
@@ -297,7 +324,7 @@ static int launch_swm(const void* q, const void* k, const void* v, const float* 
   int maxrows = 0;
   for (int c = 0; c < S; ++c) maxrows = std::max(maxrows, tab.rows[c]);
   if (maxrows > 64) return -1;     // long tables (quant_size 50): the products outweigh the gathers - not served here
-  const int TS = ((maxrows + 31) & ~31) + 4;      // table tiles go in pairs
+  const int TS = ((maxrows + 15) & ~15) + 4;
   const int nB = std::max(16 * TS, maxrows * (D + 4));
   const char* ab = getenv("PTV3_SWIN_ABLATE");      // timing experiments only: wrong results
   const int ablate = ab ? atoi(ab) : 0;

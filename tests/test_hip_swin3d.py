@@ -118,6 +118,31 @@ def test_crse_attention_dense_windows_and_shift(dev):
     assert _rel(got, want) <= 1e-4, _rel(got, want)
 
 
+@pytest.mark.parametrize("hd", [8, 16, 32])
+@pytest.mark.parametrize("crse", ["XYZ", "XYZ_RGB", "XYZ_RGB_NORM"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_crse_attention_matrix_core_kernel_vs_gather_kernel(dev, hd, crse, dtype):
+    """swin_attn_mfma_kernel (table products on the matrix core, scalar lookups in LDS: the default for short tables)
+    against swin_attn_kernel (row gathers; PTV3_SWIN_ATTN_MFMA=0) on the same inputs, every (head_dim, signal axes)
+    instantiation, windows of 1 .. 60 tokens (one to four query tiles, ragged last tiles), then against the oracle."""
+    import os
+    coords = _surface(2500, 40, hd)
+    case = _case(coords, 3, hd, 5, 4, crse, seed=hd)
+    assert case[5].min() < 16 < 33 < case[5].max()
+    got = _run(dev, case, 5, dtype)
+    os.environ["PTV3_SWIN_ATTN_MFMA"] = "0"
+    try:
+        gather = _run(dev, case, 5, dtype)
+    finally:
+        os.environ.pop("PTV3_SWIN_ATTN_MFMA", None)
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -7      # fp32: summation order only; bf16: one output rounding
+    assert np.abs(got - gather).max() <= tol * max(1.0, np.abs(gather).max())
+    if dtype == torch.float32:
+        assert not np.array_equal(got, gather)                  # two kernels did run (different summation order)
+        want = O.crse_attention(*case[:3], *case[3], *case[4:])
+        assert _rel(got, want) <= 1e-4, _rel(got, want)
+
+
 def test_crse_attention_bf16_storage(dev):
     coords = _surface(3000, 50, 5)
     case = _case(coords, 6, 16, 5, 4, "XYZ_RGB_NORM", seed=11)

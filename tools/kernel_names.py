@@ -27,7 +27,7 @@ def label(name):
     if m:
         return "window_attn_full_kernel<rpe%s,qt%s>" % (m.group(1), m.group(2))
     for k in ("window_attn_full_kernel", "window_attn_kernel", "ht_neighbors_kernel", "ht_insert_kernel",
-              "radix_scatter_kernel", "radix_hist_kernel", "knn_query_kernel", "swin_attn_bwd_kernel", "swin_attn_kernel",
+              "radix_scatter_kernel", "radix_hist_kernel", "knn_query_kernel", "swin_attn_bwd_kernel", "swin_attn_mfma_kernel", "swin_attn_kernel",
               "conv_tile_kernel"):
         if k in n:
             return k
