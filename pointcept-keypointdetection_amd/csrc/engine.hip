@@ -266,6 +266,7 @@ struct Run {
   }
 
   // sites, hash, neighbour tables and window plans of one level (geometry stream)
+  hipEvent_t stem_ready = nullptr;
   void level_geometry(Level& L, int st, const void* grid_in, int is_i64, bool need_grid64) {
     L.indices = (int32_t*)G->alloc((size_t)L.n * 16);
     L.row_order = (int32_t*)G->alloc((size_t)L.n * 4);
@@ -280,6 +281,8 @@ struct Run {
     if (st == 0) {
       L.nbr5 = (int32_t*)G->alloc((size_t)L.n * 125 * 4);
       RUN(ptv3_subm_neighbors(L.indices, L.n, L.table, L.slots, 5, L.nbr5, sg));
+      // the stem conv needs the 5^3 table and the row order only: it starts here, under the 3^3 table and the window plans
+      if (!dry && ok() && stem_ready) (void)hipEventRecord(stem_ready, sg);
     }
     L.nbr3 = (int32_t*)G->alloc((size_t)L.n * 27 * 4);
     RUN(ptv3_subm_neighbors(L.indices, L.n, L.table, L.slots, 3, L.nbr3, sg));
@@ -456,6 +459,7 @@ static int run_forward(Exec* X, const ptv3_model_desc* d, const void* const* par
     void* ws = G.alloc(wsb);
     RUNR(ptv3_argsort_i64(L0.code, k, io->n, std::max(1, 3 * depth + nbits), L0.order, L0.inverse, ws, wsb, sg));
   }
+  if (!dry) R.stem_ready = X->event_at(19);
   R.level_geometry(L0, 0, io->grid_coord, io->coord_is_i64, true);
   if (io->stage_points_host) io->stage_points_host[0] = L0.n;
   if (!dry && R.ok()) { L0.ready = X->event_at(1); (void)hipEventRecord(L0.ready, sg); }
@@ -466,7 +470,7 @@ static int run_forward(Exec* X, const ptv3_model_desc* d, const void* const* par
   // parameter walk order (header): stem, enc stage 0 blocks, [down, blocks] ..., decoder, head.
   const void* stem_w = R.next(); const float* stem_s = (const float*)R.next(); const float* stem_t = (const float*)R.next();
   {
-    wait_level(L0);
+    if (!dry && R.ok()) (void)hipStreamWaitEvent(sf, R.stem_ready, 0);
     const int C0 = d->enc_channels[0];
     L0.feat = F.alloc((size_t)L0.n * C0 * es); L0.channels = C0;
     const void* feat_in = io->feat;
@@ -480,6 +484,7 @@ static int run_forward(Exec* X, const ptv3_model_desc* d, const void* const* par
     R.gemm(feat_in, stem_w, L0.feat, L0.n, d->in_channels, C0, 125, L0.nbr5, L0.row_order, nullptr, stem_s, stem_t,
            PTV3_ACT_GELU, nullptr, nullptr, nullptr);
     L0.conv_feat = L0.feat;
+    wait_level(L0);    // the blocks need the 3^3 table and the window plans
   }
   for (int st = 0; st < S; ++st) {
     Level& L = lv[st];

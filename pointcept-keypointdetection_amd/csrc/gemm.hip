@@ -705,16 +705,18 @@ template <int N> __device__ __forceinline__ void gc_wait_vm() { asm volatile("s_
 // the kernel waits for them (measured 1.77 us per K-step against 0.85 us of matrix-core work); four stages of 64
 // bytes hold the same LDS and keep two to three stages in flight.
 template <typename T, int BN, int KB, int NSTG>
-__global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
+__global__ void __launch_bounds__(BN >= 128 ? GC_THREADS : GC_THREADS / 2) conv_tile_kernel(GemmArgs a) {
   typedef Frag<T> F;
   typedef typename F::type FR;
   constexpr int KS = KB / 64;                    // matrix-core K chunks per stage (16-byte fragments x 4 lane groups)
   constexpr int BK = KS * F::KC;                 // K elements per stage
-  constexpr int WN = BN / 64, WM = 8 / WN;       // waves across channels / points
+  constexpr int NW = BN >= 128 ? 8 : 4;          // waves: 64 output channels are one wave column of four 64-point rows
+  constexpr int NTH = 64 * NW;
+  constexpr int WN = BN >= 128 ? BN / 64 : 1, WM = NW / WN;   // waves across channels / points
   constexpr int MI = GC_BM / (16 * WM), NJ = 4;  // accumulator fragments per wave: MI x NJ (8 x 4 | 4 x 4)
   constexpr int STG = (GC_BM + BN) * KB;         // bytes per stage
   constexpr int RPI = 1024 / KB;                 // rows per copy instruction (8 | 16), KB / 16 lanes per row
-  constexpr int XQ = GC_BM / RPI / 8, WQ = BN / RPI / 8;   // copies per wave and stage
+  constexpr int XQ = GC_BM / RPI / NW, WQ = BN / RPI / NW;   // copies per wave and stage
   constexpr int DPS = XQ + WQ;
   constexpr int NGRP = KS * (MI / 4);            // fragment groups per stage
   constexpr int AH = NSTG - 1;                   // stages issued ahead
@@ -735,26 +737,32 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
   const int64_t row0 = (int64_t)(logical / ntn) * GC_BM;
   const int n0 = (int)(logical % ntn) * BN;
   const int ktot = a.kvol * a.cin;
-  const int nsteps = ktot / BK;
+  // split-K (a.slab): blockIdx.y takes steps [step_lo, step_lo + nsteps) and leaves raw fp32 partial sums in slab z -
+  // the same step boundaries, accumulation order and slab layout as gemm_kernel's splits (bitwise the same slabs)
+  const int step_lo = a.slab ? (int)blockIdx.y * a.steps_per_split : 0;
+  const int nsteps = a.slab ? min(ktot / BK - step_lo, a.steps_per_split) : ktot / BK;
 
   {
     // neighbour rows of the tile's 256 points -> LDS: two threads per point, 14 taps each, every load of a thread in
     // flight at once (an element-strided loop makes 14 dependent row_order -> nbr round trips: 20 us of a 190 us launch)
-    const int pr = tid >> 1, d0 = (tid & 1) * 14;
-    const int64_t r = row0 + pr;
-    const bool in = r < a.m;
-    const int64_t orow = in ? (a.row_order ? (int64_t)a.row_order[r] : r) : 0;
-    int32_t v[14];
 #pragma unroll
-    for (int u = 0; u < 14; ++u) {
-      const int d = d0 + u;
-      v[u] = a.nbr[orow * a.kvol + (d < a.kvol ? d : 0)];
+    for (int half = tid; half < 2 * GC_BM; half += NTH) {
+      const int pr = half >> 1, d0 = (half & 1) * 14;
+      const int64_t r = row0 + pr;
+      const bool in = r < a.m;
+      const int64_t orow = in ? (a.row_order ? (int64_t)a.row_order[r] : r) : 0;
+      int32_t v[14];
+#pragma unroll
+      for (int u = 0; u < 14; ++u) {
+        const int d = d0 + u;
+        v[u] = a.nbr[orow * a.kvol + (d < a.kvol ? d : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < 14; ++u)
+        if (d0 + u < a.kvol) sNbr[pr * a.kvol + d0 + u] = in ? v[u] : -1;
     }
-#pragma unroll
-    for (int u = 0; u < 14; ++u)
-      if (d0 + u < a.kvol) sNbr[pr * a.kvol + d0 + u] = in ? v[u] : -1;
   }
-  park_epi(a, sEpi, BN, n0, tid, GC_THREADS);
+  if (!a.slab) park_epi(a, sEpi, BN, n0, tid, NTH);
 
   const __amdgpu_buffer_rsrc_t xrs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
@@ -774,33 +782,33 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
   unsigned woff[WQ];    // byte offset of (channel row, source chunk) in w, or out of range
 #pragma unroll
   for (int i = 0; i < XQ; ++i) {
-    const int r = RPI * (wave + 8 * i) + rr;
+    const int r = RPI * (wave + NW * i) + rr;
     xnb[i] = r * a.kvol;
     xcol[i] = (unsigned)((cch ^ swz(r)) * 16);
   }
 #pragma unroll
   for (int i = 0; i < WQ; ++i) {
-    const int r = RPI * (wave + 8 * i) + rr;
+    const int r = RPI * (wave + NW * i) + rr;
     const int o = n0 + r;
     woff[i] = o < a.cout ? (unsigned)(((int64_t)o * ktot) * (int)sizeof(T)) + (unsigned)((cch ^ swz(r)) * 16) : 0xFFFFFFF0u;
   }
   const unsigned row_bytes = (unsigned)(a.cin * (int)sizeof(T));
   auto issue = [&](int step) {
     char* buf = stg + (step % NSTG) * STG;
-    const int k0 = step * BK;
+    const int k0 = (step_lo + step) * BK;
     const int d = a.cin_shift >= 0 ? (k0 >> a.cin_shift) : (k0 / a.cin);
     const unsigned kb = (unsigned)((k0 - d * a.cin) * (int)sizeof(T));   // byte offset of the stage's channels in a row of x
 #pragma unroll
     for (int i = 0; i < XQ; ++i) {
       const int src = sNbr[xnb[i] + d];
       const unsigned off = src >= 0 ? (unsigned)src * row_bytes + kb + xcol[i] : 0xFFFFFFF0u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, PTV3_LDS_PTR(buf + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, PTV3_LDS_PTR(buf + (wave + NW * i) * 1024), 16, off, 0, 0, 0);
     }
     const unsigned kw = (unsigned)(k0 * (int)sizeof(T));
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
       const unsigned off = woff[i] == 0xFFFFFFF0u ? woff[i] : woff[i] + kw;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, PTV3_LDS_PTR(buf + GC_BM * KB + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, PTV3_LDS_PTR(buf + GC_BM * KB + (wave + NW * i) * 1024), 16, off, 0, 0, 0);
     }
   };
 
@@ -864,9 +872,23 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
       __builtin_amdgcn_sched_group_barrier(0x008, MPG - 1, 0);
     });
   }
-  __syncthreads();   // operand images are dead: the output tile takes their place
-
   // ---- epilogue: lane owns point (16 (MI wr + m) + li), channels n0 + 16 (NJ wc + j) + 4g .. +3
+  if (a.slab) {
+#pragma unroll
+    for (int m = 0; m < MI; ++m) {
+      const int64_t prow = row0 + (MI * wr + m) * 16 + li;
+      if (prow >= a.m) continue;
+      const int64_t orow = a.row_order ? (int64_t)a.row_order[prow] : prow;
+      float* dst = a.slab + ((int64_t)blockIdx.y * a.m + orow) * a.cout + n0 + 4 * g;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ch = (NJ * wc + j) * 16;
+        if (n0 + ch + 4 * g < a.cout) *reinterpret_cast<f32x4*>(dst + ch) = acc[m][j];    // cout % 8 == 0 (policy)
+      }
+    }
+    return;
+  }
+  __syncthreads();   // operand images are dead: the output tile takes their place
   constexpr int OS = BN + 16 / (int)sizeof(T);
   T* sOut = reinterpret_cast<T*>(gc_smem);
 #pragma unroll
@@ -877,16 +899,32 @@ __global__ void __launch_bounds__(GC_THREADS) conv_tile_kernel(GemmArgs a) {
       stage_values<T>(a, sOut, OS, (MI * wr + m) * 16 + li, (NJ * wc + j) * 16 + 4 * g, ev, acc[m][j]);
   }
   __syncthreads();
-  store_tile<T, 8>(a, sOut, OS, GC_BM, BN, row0, n0, tid, GC_THREADS);
+  store_tile<T, 8>(a, sOut, OS, GC_BM, BN, row0, n0, tid, NTH);
 }
 
 // the 256-point tile is one workgroup per CU: it pays when its grid fills most of a round of 256 CUs
-static bool use_conv_tile(int64_t m, int cin, int cout, int kvol, int dtype, int64_t x_bytes, int* bn_out) {
+static bool use_conv_tile(int64_t m, int cin, int cout, int kvol, int dtype, int64_t x_bytes, int* bn_out, int splits) {
   const char* env = getenv("PTV3_CONV_TILE");   // 0 off, 1 policy (default), 2 force; read per call so tests can switch
   const int mode = env ? atoi(env) : 1;
   const int bk = dtype == PTV3_F32 ? 32 : 64, gran = dtype == PTV3_F32 ? 4 : 8;
-  if (mode == 0 || x_bytes <= 0 || kvol > GB_MAX_KVOL || kvol < 2 || cin % bk != 0 || cout % gran != 0 || cout < 128)
+  // 64 output channels (the C = 64 levels: 10^4 .. 10^5 sites): a four-wave workgroup, 256 points x 64 channels.
+  // PTV3_CONV_TILE_64 = 1 to enable (measurement switch)
+  const char* e64 = getenv("PTV3_CONV_TILE_64");
+  const bool narrow = cout == 64 && dtype == PTV3_BF16 && e64 && atoi(e64) != 0;
+  if (mode == 0 || x_bytes <= 0 || kvol > GB_MAX_KVOL || kvol < 2 || cin % bk != 0 || cout % gran != 0 || (cout < 128 && !narrow))
     return false;
+  if (narrow) {
+    *bn_out = 64;
+    return splits > 1 || mode == 2 || cdiv(m, GC_BM) >= 160;
+  }
+  if (splits > 1) {
+    // the deep levels of a 100k-point scene (10^2 .. 10^4 sites at C = 128 .. 512): the K range of every split-K slab
+    // through the 256-point tile (128 channels: more workgroups) instead of four 64-point tiles re-reading W -
+    // 22 -> ~11 us per convolution, the slabs and their consumers unchanged.  PTV3_CONV_TILE_SPLIT=0: off
+    const char* se = getenv("PTV3_CONV_TILE_SPLIT");
+    *bn_out = 128;
+    return cout % 8 == 0 && !(se && atoi(se) == 0);
+  }
   const int bn = (dtype == PTV3_BF16 && cout >= 256) ? 256 : 128;
   *bn_out = bn;
   if (mode == 2) return true;
@@ -1042,31 +1080,43 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
                               ((double)m * cin * (nbr ? 1 : kvol) + (double)cout * kvol * cin +
                                (double)m * cout * (1 + (res != nullptr) + (out2 != nullptr))) * esz,
                               nbr, m * kvol, 2.0 * cin * cout);
+  auto reduce_slabs = [&]() {
+    GemmArgs r = a;
+    r.row_order = nullptr;  // slabs are indexed by output row already
+    const int64_t work = m * ((cout + 3) / 4);
+    if (dtype == PTV3_F32)
+      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
+  };
   int ct_bn = 0;
-  const bool ctile = splits <= 1 && out != nullptr && nbr != nullptr && use_conv_tile(m, cin, cout, kvol, dtype, x_bytes, &ct_bn);
+  const bool ctile = nbr != nullptr && (out != nullptr || splits > 1) && use_conv_tile(m, cin, cout, kvol, dtype, x_bytes, &ct_bn, splits);
   if (ctile) {
     prof_kernel(prof, PK_CONV_TILE);
     // both ring shapes hold (256 + bn) x 256 bytes of operands: 2 stages x 128 bytes of K (default; LiDAR 120k forward
     // 9.34 ms against 9.55 ms) or 4 x 64 (PTV3_CONV_STAGES=4)
     const char* st_env = getenv("PTV3_CONV_STAGES");
-    const bool four = st_env && atoi(st_env) == 4;
+    const bool four = st_env && atoi(st_env) == 4 && splits <= 1;   // split-K steps are 128 bytes of K (steps_per_split)
     const size_t lds_ops = (size_t)(GC_BM + ct_bn) * 256 + (size_t)GC_BM * GB_MAX_KVOL * 4;
     const size_t lds_out = (size_t)GC_BM * (ct_bn * esz + 16);
     const size_t lds = std::max(lds_ops, lds_out) + (size_t)3 * ct_bn * sizeof(float);
     PTV3_REQUIRE(lds <= 160 * 1024, "conv tile: %zu bytes of LDS", lds);
-    dim3 cgrid((unsigned)(cdiv(m, GC_BM) * cdiv(cout, ct_bn)));
+    dim3 cgrid((unsigned)(cdiv(m, GC_BM) * cdiv(cout, ct_bn)), (unsigned)std::max(splits, 1));
 #define GC_LAUNCH(T, BN_, KB_, NS_)                                                                              \
     do {                                                                                                         \
       ensure_dynamic_lds(reinterpret_cast<const void*>(&conv_tile_kernel<T, BN_, KB_, NS_>), 160 * 1024);        \
-      hipLaunchKernelGGL((conv_tile_kernel<T, BN_, KB_, NS_>), cgrid, dim3(GC_THREADS), lds, s, a);              \
+      hipLaunchKernelGGL((conv_tile_kernel<T, BN_, KB_, NS_>), cgrid, gc_threads, lds, s, a);              \
     } while (0)
 #define GC_PICK(T, BN_) do { if (four) GC_LAUNCH(T, BN_, 64, 4); else GC_LAUNCH(T, BN_, 128, 2); } while (0)
+    const dim3 gc_threads(ct_bn == 64 ? GC_THREADS / 2 : GC_THREADS);
     if (dtype == PTV3_F32) GC_PICK(float, 128);
     else if (ct_bn == 256) GC_PICK(__bf16, 256);
+    else if (ct_bn == 64) GC_PICK(__bf16, 64);
     else GC_PICK(__bf16, 128);
 #undef GC_PICK
 #undef GC_LAUNCH
     prof_end(prof, s);
+    if (splits > 1 && out != nullptr) reduce_slabs();
     PTV3_LAUNCH_CHECK();
     return PTV3_OK;
   }
@@ -1137,15 +1187,7 @@ extern "C" int ptv3_gemm(const void* x, const void* w, void* out, int64_t m, int
 #undef GM_PD
 #undef GM_LAUNCH
   prof_end(prof, s);   // the bracket times the GEMM launch alone (the slab reduce below is its own, tiny kernel)
-  if (splits > 1 && out != nullptr) {
-    GemmArgs r = a;
-    r.row_order = nullptr;  // slabs are indexed by output row already
-    const int64_t work = m * ((cout + 3) / 4);
-    if (dtype == PTV3_F32)
-      hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
-    else
-      hipLaunchKernelGGL(splitk_reduce_kernel<__bf16>, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, s, r, splits);
-  }
+  if (splits > 1 && out != nullptr) reduce_slabs();
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -131,3 +131,41 @@ def test_sparse_conv_256_point_tile(dev, dtype, n, cin, cout):
     ref = torch.relu(ref * scale.cpu() + shift.cpu())
     tol = 1e-4 if dtype == torch.float32 else 2.0 ** -6
     assert (t0.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c", [(5600, 128), (1400, 256), (300, 512), (257, 128)])
+def test_sparse_conv_split_k_through_the_256_point_tile(dev, dtype, n, c):
+    """Deep levels of a 100k-point scene: the conv is split over K into fp32 slabs.  conv_tile_kernel (grid.y = split)
+    must leave bitwise the slabs of gemm_kernel's splits (PTV3_CONV_TILE_SPLIT=0): same step boundaries, same order;
+    then the reduced + epilogue'd output (out != NULL) the same way, and against the conv restatement."""
+    from ptv3_hip import ops
+    import ptv3_scenes as S
+    from oracle import ptv3 as O
+    sc = S.make_scene(n, 4, 24 if n < 2000 else 48, seed=n)
+    idx = torch.cat([torch.zeros(n, 1, dtype=torch.int32), torch.from_numpy(sc["grid_coord"]).int()], 1).contiguous()
+    g = torch.Generator().manual_seed(n + c)
+    feat = torch.randn(n, c, generator=g)
+    w = torch.randn(c, 3, 3, 3, c, generator=g) / (27 * c) ** 0.5
+    bias = torch.randn(c, generator=g)
+    nbr, _ = ops.subm_neighbors(idx.to(dev), 3)
+    order = torch.randperm(n, generator=g).int().to(dev)
+    xd, wd = feat.to(dev, dtype), w.reshape(c, -1).to(dev, dtype).contiguous()
+
+    def both(fn):
+        out = []
+        for v in ("0", "1"):
+            os.environ["PTV3_CONV_TILE_SPLIT"] = v
+            try:
+                out.append(fn())
+            finally:
+                os.environ.pop("PTV3_CONV_TILE_SPLIT", None)
+        return out
+    (s0, k0), (s1, k1) = both(lambda: ops.conv_slabs(xd, wd, nbr, 27, order))
+    assert k0 == k1 > 1
+    assert torch.equal(s0, s1)
+    o0, o1 = both(lambda: ops.gemm(xd, wd, bias=bias.to(dev), nbr=nbr, kvol=27, row_order=order, act=ops.ACT_RELU))
+    assert torch.equal(o0, o1)
+    ref = torch.relu(O.subm_conv3d(xd.float().cpu(), idx, wd.float().cpu().reshape(w.shape), bias))
+    tol = 1e-4 if dtype == torch.float32 else 2.0 ** -6
+    assert (o1.float().cpu() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())

@@ -50,7 +50,7 @@ def unfused_tail(q, f1):
 
 def main():
     check_m = int(os.environ.get("WIDE_CHECK_M", "24653"))
-    for c in (() if os.environ.get("WIDE_NO_CHECK") else (128, 256)):
+    for c in (() if os.environ.get("WIDE_NO_CHECK") else tuple(int(v) for v in os.environ.get("WIDE_CHECK_CS", "128,256").split(","))):
         p = make(c, check_m, c)
         f1_ref, qkv_ref, out_ref = reference(p, c)
         for dtype, tol in ((torch.float32, 1e-4), (torch.bfloat16, None)):
