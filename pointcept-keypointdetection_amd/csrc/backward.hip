@@ -17,46 +17,65 @@ namespace ptv3 {
 // z, z+16, ... in order, the 16 lane sums are then added in lane order (fixed tree: deterministic).  (With 16 columns per
 // block the reads were 64-byte pieces: 59 us for the ~30 MB of slabs of one block backward.)
 constexpr int SS_COLS = 64, SS_LANES = 16;
+// V = 4: a thread owns four consecutive columns (16-byte loads: a wave reads 1 KB of one slab row per instruction; the
+// scalar form's 256-byte pieces left the reductions of one block backward at ~500 GB/s, 60 us); same per-element order.
+template <int V>
 __device__ __forceinline__ void slab_sum_body(const float* __restrict__ slab, int nslab, long long n, float* __restrict__ out,
                                               long long n0, float* __restrict__ out1, long long col_block) {
-  __shared__ float red[SS_LANES][SS_COLS + 1];
+  typedef float VT __attribute__((ext_vector_type(V)));
+  __shared__ float red[SS_LANES][V * SS_COLS + 4];
   const int c = threadIdx.x & (SS_COLS - 1), z0 = threadIdx.x / SS_COLS;
-  const long long j = col_block * SS_COLS + c;
-  float s = 0.f;
+  const long long j = (col_block * SS_COLS + c) * V;
+  float s[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) s[e] = 0.f;
   if (j < n) {
     // eight loads in flight per lane, added in slab order (the sum is the same chain as a plain loop: one load per
-    // trip made every addition wait a full memory round trip - 59 us for the reductions of one block backward)
+    // trip made every addition wait a full memory round trip)
     int z = z0;
     for (; z + 7 * SS_LANES < nslab; z += 8 * SS_LANES) {
-      float v[8];
+      VT v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = slab[(long long)(z + u * SS_LANES) * n + j];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const VT*>(slab + (long long)(z + u * SS_LANES) * n + j);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int e = 0; e < V; ++e) s[e] += V == 1 ? ((const float*)&v[u])[0] : ((const float*)&v[u])[e];
     }
-    for (; z < nslab; z += SS_LANES) s += slab[(long long)z * n + j];
+    for (; z < nslab; z += SS_LANES) {
+      const VT v = *reinterpret_cast<const VT*>(slab + (long long)z * n + j);
+#pragma unroll
+      for (int e = 0; e < V; ++e) s[e] += ((const float*)&v)[e];
+    }
   }
-  red[z0][c] = s;
+#pragma unroll
+  for (int e = 0; e < V; ++e) red[z0][V * c + e] = s[e];
   __syncthreads();
   if (z0 == 0 && j < n) {
-    float t = 0.f;
 #pragma unroll
-    for (int z = 0; z < SS_LANES; ++z) t += red[z][c];
-    if (j < n0) out[j] = t; else out1[j - n0] = t;   // entries n0 .. n-1 of a slab row go to a second buffer
+    for (int e = 0; e < V; ++e) {
+      float t = 0.f;
+#pragma unroll
+      for (int z = 0; z < SS_LANES; ++z) t += red[z][V * c + e];
+      if (j + e < n0) out[j + e] = t; else out1[j + e - n0] = t;   // entries n0 .. n-1 of a slab row go to a second buffer
+    }
   }
 }
+static inline bool slab_vec4(const float* slab, long long n) { return n % 4 == 0 && ((uintptr_t)slab & 15) == 0; }
+static inline int slab_blocks(const float* slab, long long n) { return (int)cdiv(n, SS_COLS * (slab_vec4(slab, n) ? 4 : 1)); }
 
 __global__ void __launch_bounds__(SS_COLS * SS_LANES) slab_sum_kernel(const float* __restrict__ slab, int nslab, int64_t n,
                                                                       float* __restrict__ out, int64_t n0,
-                                                                      float* __restrict__ out1) {
-  slab_sum_body(slab, nslab, n, out, n0, out1, blockIdx.x);
+                                                                      float* __restrict__ out1, int vec) {
+  if (vec) slab_sum_body<4>(slab, nslab, n, out, n0, out1, blockIdx.x);
+  else slab_sum_body<1>(slab, nslab, n, out, n0, out1, blockIdx.x);
 }
 
 // Deferred reductions: a caller that issues several slab-producing kernels back to back (the native block backward:
 // six weight gradients and three LayerNorm backward passes) can collect their reductions and run them as ONE launch at
 // the end - each reduction alone is a few microseconds of work behind a full launch (242 such launches were 1.6 ms of
 // the fork model's training step).  Every deferred producer must own its slab memory until the flush.
-struct SlabSeg { const float* slab; float* out; float* out1; long long n, n0; int nslab, first_block; };
+struct SlabSeg { const float* slab; float* out; float* out1; long long n, n0; int nslab, first_block, vec; };
 constexpr int SLAB_SEGS = 16;
 struct SlabSegs { SlabSeg v[SLAB_SEGS]; };
 static thread_local SlabSegs* g_defer = nullptr;
@@ -68,7 +87,8 @@ __global__ void __launch_bounds__(SS_COLS * SS_LANES) slab_sum_multi_kernel(Slab
   for (int t = 1; t < nseg; ++t)
     if (segs.v[t].first_block <= (int)blockIdx.x) k = t;
   const SlabSeg g = segs.v[k];
-  slab_sum_body(g.slab, g.nslab, g.n, g.out, g.n0, g.out1, (int)blockIdx.x - g.first_block);
+  if (g.vec) slab_sum_body<4>(g.slab, g.nslab, g.n, g.out, g.n0, g.out1, (int)blockIdx.x - g.first_block);
+  else slab_sum_body<1>(g.slab, g.nslab, g.n, g.out, g.n0, g.out1, (int)blockIdx.x - g.first_block);
 }
 
 int slab_defer_flush(hipStream_t s) {
@@ -91,11 +111,12 @@ static void slab_sum(const float* slab, int nslab, int64_t n, float* out, hipStr
     SlabSeg& g = g_defer->v[g_defer_count++];
     g.slab = slab; g.out = out; g.out1 = out1; g.n = n; g.n0 = n0 < 0 ? n : n0; g.nslab = nslab;
     g.first_block = g_defer_blocks;
-    g_defer_blocks += (int)cdiv(n, SS_COLS);
+    g.vec = slab_vec4(slab, n) ? 1 : 0;
+    g_defer_blocks += slab_blocks(slab, n);
     return;
   }
-  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)cdiv(n, SS_COLS)), dim3(SS_COLS * SS_LANES), 0, s, slab, nslab, n,
-                     out, n0 < 0 ? n : n0, out1);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3((unsigned)slab_blocks(slab, n)), dim3(SS_COLS * SS_LANES), 0, s, slab, nslab, n,
+                     out, n0 < 0 ? n : n0, out1, slab_vec4(slab, n) ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
