@@ -93,27 +93,63 @@ radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift, uint3
   hist[((int64_t)row * nblk + blockIdx.x) * 256 + threadIdx.x] = h[threadIdx.x];
 }
 
-// one 256-thread block per row: exclusive scan, in (digit, block) order, of the [block][digit] counters.
-// thread d owns digit d: sums its nblk block counters, the 256 digit totals are scanned across the block,
-// then the thread rewrites its counters as running bases.
-__global__ void __launch_bounds__(256) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk) {
+// one 1024-thread block per row: exclusive scan, in (digit, block) order, of the [block][digit] counters.
+// Thread (part, d) owns digit d of a quarter of the blocks: sums its counters (eight loads in flight), the 256 digit
+// totals are scanned across the first four waves, then the thread rewrites its counters as running bases.
+// (One thread per digit walking all blocks twice was a chain of 2 nblk dependent round trips: 110 us per pass for
+// the 489 blocks of a 1M-voxel Swin3D level, 6 ms of its 96 ms forward.)
+constexpr int RSC_PARTS = 4;
+__global__ void __launch_bounds__(256 * RSC_PARTS) radix_scan_kernel(uint32_t* __restrict__ hist, int nblk) {
   __shared__ uint32_t wsum[4];
-  uint32_t* h = hist + (int64_t)blockIdx.x * nblk * 256 + threadIdx.x;  // stride 256 between blocks
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ uint32_t ptot[RSC_PARTS][256];
+  __shared__ uint32_t dbase[256];
+  const int d = threadIdx.x & 255, part = threadIdx.x >> 8;
+  uint32_t* h = hist + (int64_t)blockIdx.x * nblk * 256 + d;  // stride 256 between blocks
+  const int q = (nblk + RSC_PARTS - 1) / RSC_PARTS;
+  const int b0 = min(part * q, nblk), b1 = min(b0 + q, nblk);
   uint32_t total = 0;
-  for (int b = 0; b < nblk; ++b) total += h[(int64_t)b * 256];
-  uint32_t x = total;
+  int b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    uint32_t v[8];
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(x, d, 64);
-    if (lane >= d) x += t;
+    for (int u = 0; u < 8; ++u) v[u] = h[(int64_t)(b + u) * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) total += v[u];
   }
-  if (lane == 63) wsum[wave] = x;
+  for (; b < b1; ++b) total += h[(int64_t)b * 256];
+  ptot[part][d] = total;
   __syncthreads();
-  uint32_t base = x - total;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  for (int b = 0; b < nblk; ++b) {
-    uint32_t c = h[(int64_t)b * 256];
+  if (part == 0) {
+    const int lane = d & 63, wave = d >> 6;
+    uint32_t tot = 0;
+#pragma unroll
+    for (int p = 0; p < RSC_PARTS; ++p) tot += ptot[p][d];
+    uint32_t x = tot;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      uint32_t t = __shfl_up(x, k, 64);
+      if (lane >= k) x += t;
+    }
+    if (lane == 63) wsum[wave] = x;
+    dbase[d] = x - tot;        // exclusive within the wave; the wave offsets are added below
+  }
+  __syncthreads();
+  uint32_t base = dbase[d];
+  for (int w = 0; w < (d >> 6); ++w) base += wsum[w];
+  for (int p = 0; p < part; ++p) base += ptot[p][d];
+  b = b0;
+  for (; b + 8 <= b1; b += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = h[(int64_t)(b + u) * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      h[(int64_t)(b + u) * 256] = base;
+      base += v[u];
+    }
+  }
+  for (; b < b1; ++b) {
+    const uint32_t c = h[(int64_t)b * 256];
     h[(int64_t)b * 256] = base;
     base += c;
   }
@@ -421,7 +457,7 @@ extern "C" int ptv3_argsort_i64(const int64_t* code, int k, int64_t n, int end_b
     hipLaunchKernelGGL(radix_hist_kernel, grid, block, 0, s, kin, n, shift, hist, nblk);
     static const bool allow_fused = getenv("PTV3_RADIX_SEPARATE_SCAN") == nullptr;
     const bool fused = allow_fused && nblk <= RS_FUSED_SCAN_MAX_BLOCKS;
-    if (!fused) hipLaunchKernelGGL(radix_scan_kernel, dim3(k), dim3(256), 0, s, hist, nblk);
+    if (!fused) hipLaunchKernelGGL(radix_scan_kernel, dim3(k), dim3(256 * RSC_PARTS), 0, s, hist, nblk);
     uint64_t* kout = kbuf[p & 1];
     uint32_t* vout = vbuf[p & 1];
 #define RS_SCATTER(F, L)                                                                                          \
