@@ -391,6 +391,20 @@ int ptv3_window_attn_varlen_bwd(const void* qkv, const void* out, const void* do
                                 const int32_t* win_inverse, const int32_t* cu_seqlens, int num_windows, void* dqkv,
                                 int64_t n, int64_t n_pad, int c, int heads, int max_seqlen, float scale, int dtype,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* Attention dropout in training (reference: nn.Dropout on the attention probabilities,
+ * point_transformer_v3m1_base.py:203; flash_attn dropout_p, :211): out_i = sum_j keep_ij softmax(s)_ij v_j / (1 - p).
+ * keep_ij is a counter-based hash of (padded query slot, head, key slot in the window) and `seed` (csrc/common.h
+ * drop_keep), regenerated by the backward from the same seed - nothing is stored.  The reference's Philox stream is
+ * not reproduced: same distribution, different values.  cu_seqlens NULL: uniform windows of `patch` slots, else the
+ * ragged layout of ptv3_window_attn_varlen_fwd (patch = max_seqlen).  0 < p_drop < 1.  No rpe bias.
+ * The backward takes the forward's out, p_drop and seed; workspace as ptv3_window_attn_bwd_workspace_bytes. */
+int ptv3_window_attn_drop_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                              const int32_t* cu_seqlens, int num_windows, void* out, int64_t n, int64_t n_pad, int c,
+                              int heads, int patch, float scale, float p_drop, uint32_t seed, int dtype, void* stream);
+int ptv3_window_attn_drop_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                              const int32_t* win_inverse, const int32_t* cu_seqlens, int num_windows, void* dqkv,
+                              int64_t n, int64_t n_pad, int c, int heads, int patch, float scale, float p_drop,
+                              uint32_t seed, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* backward of ptv3_window_attn_rpe_fwd: dqkv as above with the relative-position bias inside the recomputed softmax,
  * plus the gradient of the bias table, dtable (3*(2*pos_bnd+1), heads) fp32 = sum over all (window, query, key) pairs
  * of dS routed to the three (axis, clamped coordinate difference) entries the pair read (RPE.forward,

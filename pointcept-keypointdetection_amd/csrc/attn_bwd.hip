@@ -10,6 +10,7 @@
 // stationary index on the lane, which is exactly the B-operand layout of the next product (dS / P never
 // touch LDS).  The gather through win_order is fused into the loads; gradients are produced per padded slot
 // and folded back to points afterwards (a borrowed point sits in two slots: kept slot + one duplicate).
+#include <algorithm>
 #include "common.h"
 #include "profile.h"
 #include "../../include/ptv3_hip.h"
@@ -27,6 +28,8 @@ struct AttnBwdArgs {
   // grid (n, 3) int32 voxel coordinates in point order, table (3 * rpe_num, heads) fp32; dtab_slab receives one partial
   // table-column gradient [3 * rpe_num] per workgroup of pass A (summed per head in block order afterwards)
   const int32_t* grid; const float* table; int pos_bnd; float* dtab_slab;
+  // attention dropout (common.h drop_keep): 0 = none; else the forward's threshold, seed and 1 / (1 - p)
+  unsigned drop_thr, drop_seed; float drop_scale;
 };
 
 constexpr int AB_MAX_TAB = 1024;  // 3 * (2 * pos_bnd + 1) entries of one head's table column held in LDS
@@ -193,7 +196,11 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
         const int* kg = sG + (RPE ? 3 * (16 * kt + 4 * g + r) : 0);
         if constexpr (RPE) sc += rpe_pair_bias(sTab, qg, kg, a.pos_bnd, rpe_num);
         const float p = kin ? __builtin_amdgcn_exp2f(sc - lse2) : 0.f;
-        ds[r] = p * (dp[r] - delta);
+        float dpe = dp[r];
+        if (a.drop_thr)   // d out / d P of a dropped pair is zero, of a kept one v / (1 - p); delta = dO . O already has it
+          dpe = drop_keep(((unsigned long long)(pq * a.heads + h) << 14) | (unsigned)(kc0 + 16 * kt + 4 * g + r), a.drop_seed,
+                          a.drop_thr) ? dpe * a.drop_scale : 0.f;
+        ds[r] = p * (dpe - delta);
         if constexpr (RPE) {
           // d loss / d bias(q, k) = dS: one bin per axis of this wave's copy of the column gradient
           if (kin && qv) {
@@ -326,7 +333,16 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(AttnBwdArgs a) {
         float sc = s[r] * a.scale_log2e;
         if constexpr (RPE) sc += rpe_pair_bias(sTab, sG + 3 * q, kg, a.pos_bnd, rpe_num);
         p[r] = __builtin_amdgcn_exp2f(sc - sL[q]);
-        ds[r] = p[r] * (dp[r] - sDl[q]);
+        float dpe = dp[r];
+        float pd = p[r];
+        if (a.drop_thr) {
+          const bool kp = drop_keep(((unsigned long long)((slot0 + qc0 + q) * a.heads + h) << 14) | (unsigned)jk, a.drop_seed,
+                                    a.drop_thr);
+          dpe = kp ? dpe * a.drop_scale : 0.f;
+          pd = kp ? pd * a.drop_scale : 0.f;
+        }
+        ds[r] = p[r] * (dpe - sDl[q]);
+        p[r] = pd;      // dV sums the dropped, rescaled weights
       }
       const V4 pv = pack4<T>(p[0], p[1], p[2], p[3]);
       const V4 dsv = pack4<T>(ds[0], ds[1], ds[2], ds[3]);
@@ -431,7 +447,8 @@ struct RpeBwd { const int32_t* grid; const float* table; int pos_bnd; float* dta
 static int window_attn_bwd_impl(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
                                 const int32_t* win_inverse, const int32_t* cu, int nwin, void* dqkv, int64_t n,
                                 int64_t n_pad, int c, int heads, int patch, float scale, int dtype, void* workspace,
-                                hipStream_t s, RpeBwd rpe = RpeBwd{nullptr, nullptr, 0, nullptr}) {
+                                hipStream_t s, RpeBwd rpe = RpeBwd{nullptr, nullptr, 0, nullptr}, float p_drop = 0.f,
+                                unsigned seed = 0) {
   const int d = c / heads;
   if (d != 16 && d != 32 && d != 64) {
     set_error("window_attn_bwd: head_dim %d unsupported (16, 32, 64)", d);
@@ -449,6 +466,8 @@ static int window_attn_bwd_impl(const void* qkv, const void* out, const void* do
   a.c = c; a.heads = heads; a.patch = patch; a.nwin = nwin; a.cu = cu;
   a.grid = rpe.grid; a.table = rpe.table; a.pos_bnd = rpe.pos_bnd; a.dtab_slab = (float*)ws;
   a.scale = scale; a.scale_log2e = scale * 1.44269504088896340736f;
+  a.drop_thr = p_drop > 0.f ? (unsigned)std::min(4294967295.0, (double)p_drop * 4294967296.0) : 0u;
+  a.drop_seed = seed; a.drop_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
   if (hipMemsetAsync(dup, 0xFF, (size_t)n * sizeof(int32_t), s) != hipSuccess) return PTV3_ERR_LAUNCH;
   hipLaunchKernelGGL(dup_slot_kernel, dim3((unsigned)cdiv(n_pad, 256)), dim3(256), 0, s, win_order, win_inverse, n_pad, dup);
 #define AB_CASE(T)                                     \
@@ -538,4 +557,21 @@ extern "C" int ptv3_window_attn_varlen_bwd(const void* qkv, const void* out, con
                "window_attn_varlen_bwd: workspace too small");
   return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, cu_seqlens, num_windows, dqkv, n, n_pad, c, heads,
                               max_seqlen, scale, dtype, workspace, (hipStream_t)stream);
+}
+
+extern "C" int ptv3_window_attn_drop_bwd(const void* qkv, const void* out, const void* dout, const int32_t* win_order,
+                                         const int32_t* win_inverse, const int32_t* cu_seqlens, int num_windows, void* dqkv,
+                                         int64_t n, int64_t n_pad, int c, int heads, int patch, float scale, float p_drop,
+                                         uint32_t seed, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_drop_bwd: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_drop_bwd: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(cu_seqlens != nullptr || n_pad % patch == 0, "window_attn_drop_bwd: n_pad=%lld is not a multiple of patch=%d",
+               (long long)n_pad, patch);
+  PTV3_REQUIRE(p_drop > 0.f && p_drop < 1.f, "window_attn_drop_bwd: p_drop %g outside (0,1)", (double)p_drop);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_drop_bwd: bad dtype %d", dtype);
+  PTV3_REQUIRE(workspace_bytes >= ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, heads, dtype),
+               "window_attn_drop_bwd: workspace too small");
+  const int nwin = cu_seqlens ? num_windows : (int)(n_pad / patch);
+  return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, cu_seqlens, nwin, dqkv, n, n_pad, c, heads, patch,
+                              scale, dtype, workspace, (hipStream_t)stream, RpeBwd{nullptr, nullptr, 0, nullptr}, p_drop, seed);
 }

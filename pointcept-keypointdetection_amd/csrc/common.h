@@ -152,6 +152,17 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
   return base + slot;
 }
 
+// Attention dropout (reference: torch.nn.Dropout on the attention probabilities, point_transformer_v3m1_base.py:203, or
+// flash_attn's dropout_p, :211): keep / drop of the pair (query slot, key slot) is a counter-based hash of
+// id = ((padded query slot * heads + head) << 14 | key slot in its window) and the call's seed, so the forward kernel
+// and the two backward kernels regenerate the same mask without storing it (the reference's Philox stream is not
+// reproduced: the mask is equal in distribution, not in value; tests rebuild it on the host from this function).
+__device__ __forceinline__ bool drop_keep(unsigned long long id, unsigned seed, unsigned thr) {
+  unsigned x = ((unsigned)id * 0x9E3779B1u) ^ ((unsigned)(id >> 32) * 0x85EBCA77u) ^ seed;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x >= thr;   // P(drop) = thr / 2^32
+}
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a function: set it once per (function,
 // device), under a lock (a process may drive several GPUs, and several host threads one GPU).
 inline void ensure_dynamic_lds(const void* fn, int bytes) {

@@ -6,6 +6,7 @@
 // of O^T += V^T * P^T, so P never touches LDS.
 // Reference semantics: SerializedAttention.forward, point_transformer_v3m1_base.py:184-216.
 #include <type_traits>
+#include <algorithm>
 #include "common.h"
 #include <stdlib.h>
 #include "profile.h"
@@ -27,7 +28,7 @@ __global__ void __launch_bounds__(WA_THREADS)
 window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
                    const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int Kmax,
                    int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe,
-                   const int32_t* __restrict__ cu) {
+                   const int32_t* __restrict__ cu, unsigned drop_thr = 0, unsigned drop_seed = 0, float drop_scale = 1.f) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
@@ -186,6 +187,13 @@ window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_or
         float p2 = __builtin_amdgcn_exp2f(s[kt][2] - mn);
         float p3 = __builtin_amdgcn_exp2f(s[kt][3] - mn);
         ps += (p0 + p1) + (p2 + p3);
+        if (drop_thr) {   // training with attn_drop > 0: the normaliser keeps every pair, the value sum the kept ones / (1 - p)
+          const unsigned long long id = ((unsigned long long)((wbase + qidx[t]) * H + h) << 14) | (unsigned)(key0 + 16 * kt + 4 * g);
+          p0 = drop_keep(id, drop_seed, drop_thr) ? p0 * drop_scale : 0.f;
+          p1 = drop_keep(id + 1, drop_seed, drop_thr) ? p1 * drop_scale : 0.f;
+          p2 = drop_keep(id + 2, drop_seed, drop_thr) ? p2 * drop_scale : 0.f;
+          p3 = drop_keep(id + 3, drop_seed, drop_thr) ? p3 * drop_scale : 0.f;
+        }
         pf[kt] = pack4<T>(p0, p1, p2, p3);
       }
       l[t] = l[t] * alpha + ps;
@@ -628,9 +636,65 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
   return PTV3_OK;
 }
 
+// training forward with attention dropout: always the tiled kernel (the mask costs ~12 integer operations per score; the
+// resident-window kernel stays free of it)
+template <typename T, int ND>
+static int launch_window_attn_drop(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H, int K,
+                                   int nwin, float scale, const int32_t* cu, unsigned thr, unsigned seed, float dscale,
+                                   hipStream_t s) {
+  constexpr int D = 16 * ND;
+  constexpr int QT = WaCfg<T, ND>::QT;
+  constexpr int QB = WA_WAVES * QT * 16;
+  const int qsplit = (K + QB - 1) / QB;
+  const size_t lds = (size_t)(WA_KT * (D + 4) + D * (WA_KT + 4)) * sizeof(T) + (size_t)K * 4;
+  if (lds > 64 * 1024) ensure_dynamic_lds(reinterpret_cast<const void*>(&window_attn_kernel<T, ND>), 160 * 1024);
+  const unsigned nwg = (unsigned)nwin * H * qsplit;
+  hipLaunchKernelGGL((window_attn_kernel<T, ND>), dim3(nwg), dim3(WA_THREADS), lds, s, (const T*)qkv, wo, wi, (T*)out, C, H,
+                     K, nwin, qsplit, scale * 1.44269504088896340736f, (const float*)nullptr, cu, thr, seed, dscale);
+  PTV3_LAUNCH_CHECK();
+  return PTV3_OK;
+}
+
 }  // namespace ptv3
 
 using namespace ptv3;
+
+extern "C" int ptv3_window_attn_drop_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                         const int32_t* cu_seqlens, int num_windows, void* out, int64_t n, int64_t n_pad,
+                                         int c, int heads, int patch, float scale, float p_drop, uint32_t seed, int dtype,
+                                         void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_drop: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_drop: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(cu_seqlens != nullptr || n_pad % patch == 0, "window_attn_drop: n_pad=%lld is not a multiple of patch=%d",
+               (long long)n_pad, patch);
+  PTV3_REQUIRE(p_drop > 0.f && p_drop < 1.f, "window_attn_drop: p_drop %g outside (0,1)", (double)p_drop);
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_drop: bad dtype %d", dtype);
+  const int d = c / heads;
+  if (n == 0) return PTV3_OK;
+  if (d != 16 && d != 32 && d != 64) {
+    set_error("window_attn_drop: head_dim %d unsupported (16, 32, 64)", d);
+    return PTV3_ERR_UNSUPPORTED;
+  }
+  const int nwin = cu_seqlens ? num_windows : (int)(n_pad / patch);
+  const unsigned thr = (unsigned)std::min(4294967295.0, (double)p_drop * 4294967296.0);
+  const float dscale = 1.f / (1.f - p_drop);
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = dtype == PTV3_F32 ? 4 : 2;
+  const int prof = prof_begin(s, PROF_WINDOW_ATTN, 4.0 * n_pad * patch * c,
+                              (double)n_pad * 3 * c * esz + (double)n * c * esz + 4.0 * (n_pad + n), nullptr, 0, 0.0);
+  prof_kernel(prof, PK_ATTN_TILED);
+  int rc = PTV3_ERR_UNSUPPORTED;
+#define WAD_CASE(T)                                                                                                       \
+  switch (d) {                                                                                                            \
+    case 16: rc = launch_window_attn_drop<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, cu_seqlens, thr, seed, dscale, s); break; \
+    case 32: rc = launch_window_attn_drop<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, cu_seqlens, thr, seed, dscale, s); break; \
+    default: rc = launch_window_attn_drop<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, cu_seqlens, thr, seed, dscale, s); break; \
+  }
+  if (dtype == PTV3_F32) { WAD_CASE(float) } else { WAD_CASE(__bf16) }
+#undef WAD_CASE
+  prof_end(prof, s);
+  return rc;
+}
 
 static int window_attn_fwd_impl(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
                                 const int32_t* cu, int nwin, void* out, int64_t n, int64_t n_pad, int c, int heads,

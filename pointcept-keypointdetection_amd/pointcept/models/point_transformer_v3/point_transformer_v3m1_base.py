@@ -10,8 +10,10 @@ LayerNorm, folded BatchNorm, segmented pooling.  Both `enable_flash` settings ru
 kernel.  enable_flash=False: the patch shrinks to the smallest scene (:173-176), every window has K slots.
 enable_flash=True: K is fixed, a scene with fewer than K points is ONE short window (:131-133) and the
 windows go through the ragged form of the kernel (ptv3_window_attn_varlen_fwd: the semantics of the
-flash_attn_varlen_qkvpacked_func call at :207-215, computed in the model's dtype; attention dropout of
-that call (`attn_drop` > 0 in training) is not implemented and raises).
+flash_attn_varlen_qkvpacked_func call at :207-215, computed in the model's dtype).  Attention dropout
+(`attn_drop` > 0 in training: nn.Dropout on the probabilities :203, flash_attn's dropout_p :211) runs in
+ptv3_window_attn_drop_fwd / _bwd with a hash-generated keep mask (same distribution as the reference's, not
+its Philox values); together with enable_rpe it raises.
 """
 import math
 from functools import partial
@@ -133,11 +135,13 @@ class SerializedAttention(PointModule):
             return None
         return self.get_padding_and_inverse(point)[2]
 
+    def _p_attn_drop(self):
+        return self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else float(self.attn_drop)
+
     def _check_attn_drop(self):
-        p_drop = self.attn_drop.p if isinstance(self.attn_drop, nn.Dropout) else float(self.attn_drop)
-        if p_drop > 0.0:  # the reference drops attention probabilities (:203, :211); no such kernel here
-            raise NotImplementedError("SerializedAttention: attn_drop > 0 has no training kernel on the HIP path "
-                                      "(0.0 in every PTv3 config of the reference)")
+        if self._p_attn_drop() > 0.0:  # RPE bias and attention dropout together: no kernel (no config of the reference)
+            raise NotImplementedError("SerializedAttention: attn_drop > 0 together with enable_rpe has no training "
+                                      "kernel on the HIP path")
 
     def attention_core(self, point, qkv):
         """gather -> softmax(QK^T)V -> scatter (:188-216) in one kernel."""
@@ -158,7 +162,13 @@ class SerializedAttention(PointModule):
                 return out
             bias = self.rpe(self.get_rel_pos(point, wo.long()))
         if self.training:
-            self._check_attn_drop()
+            p_drop = self._p_attn_drop()
+            if p_drop > 0.0:
+                # dropout on the attention probabilities (:203 nn.Dropout, :211 flash_attn dropout_p): the mask is a hash
+                # of (query slot, head, key slot) and a seed drawn here from torch's CPU generator (torch.manual_seed)
+                seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+                return A.window_attention_drop(qkv, wo, wi, self.num_heads, K, self.scale, p_drop, seed,
+                                               self.window_cu(point))
             return A.window_attention(qkv, wo, wi, self.num_heads, K, self.scale, self.window_cu(point))
         cu = self.window_cu(point)
         if cu is not None:

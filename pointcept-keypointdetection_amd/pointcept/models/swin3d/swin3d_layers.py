@@ -10,7 +10,8 @@ PARITY UNPINNED: the reference runs this arithmetic in MinkowskiEngine and micro
 its tree; oracle/swin3d.py restates it and is the only checker (see its header for what is an assumption).
 
 Training: every layer is a taped Function with a HIP backward (ptv3_swin_attn_bwd for the attention, the PTv3 path's
-Functions for Linear / LayerNorm / GELU); attention dropout (`attn_drop` > 0) is not implemented and raises.
+Functions for Linear / LayerNorm / GELU).  `attn_drop` is accepted and, as in the reference (the nn.Dropout of :476 is
+never applied in its forward), has no effect.
 """
 import numpy as np
 import torch
@@ -74,8 +75,8 @@ class WindowAttention(nn.Module):
             self.table_offsets += [int(np.prod(shape[1:]))] * 3
             self._groups.append((name, quant))
         self.qkv = Linear(dim, dim * 3, bias=qkv_bias)
-        if attn_drop > 0.0:
-            raise NotImplementedError("Swin3D WindowAttention: attn_drop > 0 (dropout inside the attention) is not built")
+        # the reference constructs this module (:476) and never calls it: SelfAttnAIOFunction (:556-569) has no dropout
+        # argument, so attn_drop > 0 changes nothing there - nor here
         self.attn_drop = nn.Dropout(attn_drop, inplace=True)
         self.proj = Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop, inplace=True)

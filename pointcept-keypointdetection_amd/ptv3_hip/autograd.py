@@ -259,6 +259,25 @@ class WindowAttentionFn(Function):
                 None, None, None, None, None, None)
 
 
+class WindowAttentionDropFn(Function):
+    """WindowAttentionFn with attention dropout: the mask is regenerated in the backward from (p_drop, seed)."""
+
+    @staticmethod
+    def forward(ctx, qkv, win_order, win_inverse, heads, patch, scale, p_drop, seed, cu=None):
+        qkv = qkv.contiguous()
+        out = ops.window_attention_drop(qkv, win_order, win_inverse, heads, patch, scale, p_drop, seed, cu)
+        ctx.save_for_backward(qkv, out, win_order, win_inverse, cu)
+        ctx.cfg = (heads, patch, scale, p_drop, seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, win_order, win_inverse, cu = ctx.saved_tensors
+        heads, patch, scale, p_drop, seed = ctx.cfg
+        return (ops.window_attention_drop_bwd(qkv, out, dout.contiguous(), win_order, win_inverse, heads, patch, scale,
+                                              p_drop, seed, cu), None, None, None, None, None, None, None, None)
+
+
 class WindowAttentionRpeFn(Function):
     """Window attention with the RPE bias looked up in the kernel (:29-48, :196-204): gradients for qkv AND the bias
     table (each (query, key) pair's dS goes to the three table entries it read)."""
@@ -368,6 +387,10 @@ def activation(x, act):
 
 def window_attention(qkv, win_order, win_inverse, heads, patch, scale, cu=None):
     return WindowAttentionFn.apply(qkv, win_order, win_inverse, heads, patch, scale, cu)
+
+
+def window_attention_drop(qkv, win_order, win_inverse, heads, patch, scale, p_drop, seed, cu=None):
+    return WindowAttentionDropFn.apply(qkv, win_order, win_inverse, heads, patch, scale, float(p_drop), int(seed), cu)
 
 
 def window_attention_rpe(qkv, rpe_table, win_order, win_inverse, grid_coord, heads, patch, scale, pos_bnd):

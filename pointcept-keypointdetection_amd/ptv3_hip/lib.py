@@ -1,7 +1,7 @@
 """Loads lib/libptv3_hip.so and declares the C ABI of include/ptv3_hip.h for ctypes."""
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint32, c_void_p
 
 PTV3_F32, PTV3_BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
@@ -95,6 +95,10 @@ SIGNATURES = {
                                      c_size_t, P]),
     "ptv3_window_attn_varlen_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
                                             c_int, P, c_size_t, P]),
+    "ptv3_window_attn_drop_fwd": (c_int, [P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_float,
+                                          c_uint32, c_int, P]),
+    "ptv3_window_attn_drop_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
+                                          c_float, c_uint32, c_int, P, c_size_t, P]),
     "ptv3_window_attn_rpe_bwd_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "ptv3_window_attn_rpe_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, c_int,
                                          c_float, c_int, P, c_size_t, P]),

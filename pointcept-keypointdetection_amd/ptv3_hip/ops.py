@@ -182,6 +182,62 @@ def window_attention_any(qkv, win_order, win_inverse, heads, patch, scale, cu_se
     return window_attention_varlen(qkv, win_order, win_inverse, cu_seqlens, heads, patch, scale, sum_len_sq)
 
 
+def window_attention_drop(qkv, win_order, win_inverse, heads, patch, scale, p_drop, seed, cu_seqlens=None):
+    """Training forward with attention dropout (:203 / :211): softmax over all pairs, kept pairs / (1 - p_drop) into the
+    value sum; the keep mask is a hash of (query slot, head, key slot, seed) - see drop_keep_mask()."""
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    _chk(cu_seqlens, "cu_seqlens", torch.int32, 1)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    if win_inverse.shape[0] != n:
+        raise RuntimeError("window_attention_drop: shape mismatch")
+    out = torch.empty((n, c), dtype=qkv.dtype, device=qkv.device)
+    nwin = cu_seqlens.numel() - 1 if cu_seqlens is not None else 0
+    lib.check(lib.ptv3_window_attn_drop_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(cu_seqlens), nwin, _p(out), n,
+                                            win_order.shape[0], c, int(heads), int(patch), float(scale), float(p_drop),
+                                            int(seed) & 0xFFFFFFFF, _dt(qkv), _stream()), "ptv3_window_attn_drop_fwd")
+    return out
+
+
+def window_attention_drop_bwd(qkv, out, dout, win_order, win_inverse, heads, patch, scale, p_drop, seed, cu_seqlens=None):
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(out, "out", qkv.dtype, 2)
+    _chk(dout, "dout", qkv.dtype, 2)
+    _chk(cu_seqlens, "cu_seqlens", torch.int32, 1)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    n_pad = win_order.shape[0]
+    dqkv = torch.empty_like(qkv)
+    nb = lib.ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, int(heads), _dt(qkv))
+    ws = _ws(nb, qkv.device)
+    nwin = cu_seqlens.numel() - 1 if cu_seqlens is not None else 0
+    lib.check(lib.ptv3_window_attn_drop_bwd(_p(qkv), _p(out), _p(dout), _p(win_order), _p(win_inverse), _p(cu_seqlens),
+                                            nwin, _p(dqkv), n, n_pad, c, int(heads), int(patch), float(scale),
+                                            float(p_drop), int(seed) & 0xFFFFFFFF, _dt(qkv), _p(ws), nb, _stream()),
+              "ptv3_window_attn_drop_bwd")
+    return dqkv
+
+
+def drop_keep_mask(slot, head, key, heads, seed, p_drop):
+    """Host restatement of csrc/common.h drop_keep: numpy integer arrays (broadcastable) of padded query slots, heads and
+    key slots inside the window -> boolean keep mask.  For tests and for anyone who needs the mask a call used."""
+    import numpy as np
+    idv = ((np.asarray(slot, np.uint64) * np.uint64(heads) + np.asarray(head, np.uint64)) << np.uint64(14)) | np.asarray(key, np.uint64)
+    lo = (idv & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    hi = (idv >> np.uint64(32)).astype(np.uint64)
+    m32 = np.uint64(0xFFFFFFFF)
+    x = ((lo * np.uint64(0x9E3779B1)) & m32) ^ ((hi * np.uint64(0x85EBCA77)) & m32) ^ np.uint64(int(seed) & 0xFFFFFFFF)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & m32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & m32
+    x ^= x >> np.uint64(16)
+    thr = np.uint64(min(4294967295, int(float(np.float32(p_drop)) * 4294967296.0)))
+    return x >= thr
+
+
 def window_attention_rpe(qkv, win_order, win_inverse, heads, patch, scale, grid_coord, rpe_table, pos_bnd):
     """window_attention() + the RPE bias looked up from the (3*(2*pos_bnd+1), heads) table inside the kernel.
     Returns None when the window does not fit the resident-window kernel (caller falls back to the dense bias)."""

@@ -190,14 +190,14 @@ def test_swin3d_state_dict_matches_the_reference_classes(cfg_name, listing):
     assert got == want
 
 
-def test_swin3d_refuses_what_it_does_not_build():
+def test_swin3d_constructor_variants_build():
     from ptv3_hip import configs
     from pointcept.models import build_model
     build_model(dict(configs.TINY_SWIN3D_CFG, knn_down=False))            # GridDownsample: built since round 3
     build_model(dict(configs.TINY_SWIN3D_CFG, stem_transformer=False))    # MinkResBlock stem: built since round 3
-    with pytest.raises(NotImplementedError, match="attn_drop"):
-        from pointcept.models.swin3d import WindowAttention
-        WindowAttention(32, 5, 4, 2, attn_drop=0.1)
+    from pointcept.models.swin3d import WindowAttention
+    # attn_drop: the reference builds nn.Dropout(attn_drop) (swin3d_layers.py:476) and never applies it - accepted, inert
+    assert WindowAttention(32, 5, 4, 2, attn_drop=0.1).attn_drop.p == 0.1
 
 
 def test_offset_models_report_the_reference_training_keys():

@@ -188,6 +188,48 @@ def test_window_attention_backward(dev, sizes, C, H, K):
     _close(qb.grad, qr.grad, tol=5e-2, what="dqkv bf16")
 
 
+@pytest.mark.parametrize("sizes,C,H,K,p", [([300, 200], 32, 2, 64, 0.1), ([1500], 64, 4, 256, 0.25), ([400], 128, 2, 128, 0.5),
+                                           ([2100], 32, 2, 1024, 0.1)])
+def test_window_attention_dropout_forward_and_backward(dev, sizes, C, H, K, p):
+    """attn_drop > 0 in training (reference: nn.Dropout on the probabilities, v3m1_base.py:203 / flash dropout_p :211).
+    The kernels draw the keep mask from a hash of (padded query slot, head, key slot, seed); the same mask rebuilt on
+    the host (ops.drop_keep_mask) makes torch autograd over softmax * mask / (1 - p) the exact reference for the
+    forward output and for dqkv.  The reference's own RNG stream is not reproduced (equal in distribution only)."""
+    from ptv3_hip import autograd as A, ops
+    n, order, inverse, pad, unpad = _attn_setup(sizes, K, seed=C + K)
+    g = torch.Generator().manual_seed(K)
+    qkv = torch.randn(n, 3 * C, generator=g)
+    dout = torch.randn(n, C, generator=g)
+    seed = 12345 + K
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    n_pad = len(pad)
+    W = n_pad // K
+    slot = (np.arange(W)[:, None, None, None] * K + np.arange(K)[None, None, :, None])
+    keep = ops.drop_keep_mask(slot, np.arange(H)[None, :, None, None], np.arange(K)[None, None, None, :], H, seed, p)
+    assert keep.shape == (W, H, K, K)
+    assert abs(keep.mean() - (1.0 - p)) < 0.01                      # the hash drops a fraction p of the pairs
+    mask = torch.from_numpy(keep.astype(np.float32)) / (1.0 - float(np.float32(p)))
+    qr = _leaf(qkv)
+    o, inv = t(order)[t(pad)], t(unpad)[t(inverse)]
+    q, k, v = qr[o].reshape(-1, K, 3, H, C // H).permute(2, 0, 3, 1, 4).unbind(dim=0)
+    attn = torch.softmax((q * (C // H) ** -0.5) @ k.transpose(-2, -1), dim=-1) * mask
+    ref = (attn @ v).transpose(1, 2).reshape(-1, C)[inv]
+    ref.backward(dout)
+    wo, wi = ops.window_maps(t(order).to(dev), t(inverse).to(dev), t(pad).to(dev), t(unpad).to(dev))
+    qd = _leaf(qkv, dev)
+    out = A.window_attention_drop(qd, wo, wi, H, K, (C // H) ** -0.5, p, seed)
+    out.backward(dout.to(dev))
+    _close(out, ref.detach(), what="out")
+    _close(qd.grad, qr.grad, what="dqkv")
+    # another seed is another mask; the same seed the same result
+    out2 = ops.window_attention_drop(qd.detach(), wo, wi, H, K, (C // H) ** -0.5, p, seed + 1)
+    out3 = ops.window_attention_drop(qd.detach(), wo, wi, H, K, (C // H) ** -0.5, p, seed)
+    assert not torch.equal(out2, out.detach()) and torch.equal(out3, out.detach())
+    qb = _leaf(qkv, dev, torch.bfloat16)
+    A.window_attention_drop(qb, wo, wi, H, K, (C // H) ** -0.5, p, seed).backward(dout.to(dev).bfloat16())
+    _close(qb.grad, qr.grad, tol=5e-2, what="dqkv bf16")
+
+
 def test_segment_max_and_cluster_gather_backward(dev):
     from ptv3_hip import autograd as A
     g = torch.Generator().manual_seed(3)
