@@ -49,3 +49,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/train_stats -- python
 python tools/train_kernel_stats.py "$(ls -t $O/train_stats/*/*_kernel_stats.csv | head -1)" 7 > $O/train_kernel_summary.txt 2>/dev/null || true
 head -12 $O/train_kernel_summary.txt || true
 python tools/bench_pointops.py > $O/knn_query.json 2>/dev/null; python tools/bench_pointops.py 100000 100000 16 >> $O/knn_query.json 2>/dev/null
+# ---- Swin3D (BASELINE configs[4]): attention micro-benchmark (both kernels), kernel stats of the 1M-point forward
+python tools/bench_swin.py 300000 2>/dev/null > $O/swin_attn_bench.log
+PTV3_SWIN_ATTN_MFMA=0 python tools/bench_swin.py 300000 2>/dev/null > $O/swin_attn_bench_gather.log
+rm -rf $O/swin_stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/swin_stats -- python tools/bench_swin.py 1000000 model > $O/swin1m.log 2>&1
+cp "$(ls -t $O/swin_stats/*/*_kernel_stats.csv | head -1)" $O/swin1m_kernel_stats.csv; rm -rf $O/swin_stats
+tail -1 $O/swin1m.log
