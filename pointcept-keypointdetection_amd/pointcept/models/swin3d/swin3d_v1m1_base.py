@@ -274,9 +274,10 @@ class Upsample(nn.Module):
                                     cRSE=cRSE, fp16_mode=fp16_mode)
 
     def forward(self, deep, shallow):
-        carried = pointops.interpolation(deep.xyz, shallow.xyz, self.linear2(deep.feat).contiguous(), deep.offset,
+        # pointops works in fp32 (its C API, libs/pointops: float only); under compute_dtype = bf16 the blend is fp32 too
+        carried = pointops.interpolation(deep.xyz, shallow.xyz, self.linear2(deep.feat).float().contiguous(), deep.offset,
                                          shallow.offset, k=self.up_k, cell=float(deep.stride))
-        shallow.feat = self.linear1(shallow.feat) + carried
+        shallow.feat = self.linear1(shallow.feat) + carried.to(shallow.feat.dtype)
         if self.attn:
             shallow, _ = self.block(shallow)
         return shallow
@@ -346,8 +347,16 @@ class Swin3DUNet(nn.Module):
                        _offsets(vox[:, 0], offset.shape[0]))
         return level, cluster
 
+    #: eval only.  None / torch.float32: fp32 features (default).  torch.bfloat16: features, Linear / conv operands and
+    #: q, k, v in bf16 with fp32 accumulation, LayerNorm statistics, softmax, cRSE tables, signals, kNN and interpolation
+    #: in fp32 - what the reference's S3DIS configs run under `enable_amp = True` (fp16 autocast there; bf16 here, as
+    #: for PTv3).  Logits come back in fp32.
+    compute_dtype = None
+
     def forward(self, data_dict):
         level, point2voxel = self.voxelize(data_dict)
+        if not self.training and self.compute_dtype not in (None, torch.float32):
+            level.feat = level.feat.to(self.compute_dtype)
         level = self.stem_layer(level)
         skips = []
         if self.layer_start > 0:          # :213-216
@@ -360,4 +369,4 @@ class Swin3DUNet(nn.Module):
         for up in self.upsamples:
             level = up(level, skips.pop())
         x = self.classifier[1](self.classifier[0](level.feat), act=ops.ACT_RELU)   # BN: batch statistics in training
-        return self.classifier[3](x)[point2voxel]
+        return self.classifier[3](x).float()[point2voxel]

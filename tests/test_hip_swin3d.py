@@ -348,6 +348,28 @@ def test_swin3d_s3dis_config_end_to_end_vs_the_restated_model(dev):
     assert _rel(got, want) <= 1e-4, _rel(got, want)
 
 
+def test_swin3d_bf16_compute_dtype_close_to_fp32(dev):
+    """`model.compute_dtype = torch.bfloat16` (the reference's S3DIS configs run under enable_amp = True): features,
+    GEMM / conv operands and q, k, v in bf16, everything that indexes a table or a neighbour in fp32.  Against the fp32
+    run of the same weights: logits within a few bf16 steps of the logit scale over the ~60 layers, same class for
+    nearly every point."""
+    from ptv3_hip import configs
+    from pointcept.models import build_model
+    model = build_model(dict(configs.SWIN3D_S3DIS_CFG))
+    _randomise(model, 15)
+    batch = _to_dev(_swin_batch([5000, 4000], seed=3), dev)
+    model = model.to(dev).eval()
+    with torch.no_grad():
+        ref = model(dict(batch))
+        model.compute_dtype = torch.bfloat16
+        got = model(dict(batch))
+    assert got.dtype == torch.float32 and got.shape == ref.shape
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 0.08 * scale, ((got - ref).abs().max().item(), scale)
+    assert (got - ref).abs().mean().item() <= 0.01 * scale
+    assert (got.argmax(1) == ref.argmax(1)).float().mean().item() >= 0.97
+
+
 def test_offset_keypoint_swin3d_fork_config_vs_the_restated_model(dev):
     """"OffsetKeypointSwin3D" with the fork's own config (configs/my_dataset/offset_keypoint_swin3d.py:14-38: 4 levels
     64..512 channels, 4..32 heads of 16, quant 50, XYZ_RGB, hidden 256) against the restated backbone + a numpy head."""

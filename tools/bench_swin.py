@@ -38,6 +38,8 @@ def bench_model(n, dev):
              "offset": torch.tensor([n], device=dev)}
     torch.manual_seed(0)
     model = build_model(configs.SWIN3D_S3DIS_CFG).to(dev).eval()
+    if os.environ.get("SWIN_DTYPE") == "bf16":
+        model.compute_dtype = torch.bfloat16
     with torch.no_grad():
         for _ in range(2):
             y = model(dict(batch))
@@ -47,7 +49,7 @@ def bench_model(n, dev):
             y = model(dict(batch))
         torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
-    print(json.dumps({"model": "Swin3D-v1m1 (Swin3D-S, S3DIS config)", "points": n, "dtype": "float32",
+    print(json.dumps({"model": "Swin3D-v1m1 (Swin3D-S, S3DIS config)", "points": n, "dtype": os.environ.get("SWIN_DTYPE", "float32"),
                       "ms_per_forward": round(ms, 2), "Mpoints_per_s": round(n / ms / 1e3, 3),
                       "finite": bool(torch.isfinite(y).all().item())}))
 
