@@ -5,11 +5,14 @@
 # usage (from repo root, under gpurun): bash tools/measure_round.sh r03
 set -e
 R=${1:-r03}; O=gpurun_out/$R; mkdir -p $O
+PART=${2:-ABC}     # a gpurun call is capped at 20 minutes: run the parts (A headline, B LiDAR, C train / kNN / Swin3D) in separate calls
 export TMPDIR=/tmp
 # NOTE: only gpurun_out/ travels back from the GPU box; copy the summaries into profiles/$R afterwards with
 #       tools/collect_round.sh $R (runs in the build container).
+if [[ $PART == *A* ]]; then
 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log | tail -1 > $O/bench_n1_default.json
 echo "bench done: $(cut -c1-160 $O/bench_n1_default.json)"
+fi
 pmc_pair() {  # $1 = tag, rest = bench args: FETCH / WRITE passes + SQ pass of one workload
   local tag=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -21,6 +24,7 @@ pmc_pair() {  # $1 = tag, rest = bench args: FETCH / WRITE passes + SQ pass of o
     --kernel-trace --output-format csv -d $O/pmc_${tag}_sq -- python bench.py "$@" --steps 5 --warmup 2 --cpu-sample 0 --no-extra --no-kernel-events > $O/pmc_${tag}_sq.log 2>&1
 }
 # ---- headline (100k surface scene)
+if [[ $PART == *A* ]]; then
 rm -rf $O/stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --cpu-sample 0 --no-extra > $O/bench_stats.log 2>&1
 grep '^{"metric"' $O/bench_stats.log | tail -1 > $O/bench_n1_under_rocprof.json
@@ -30,7 +34,9 @@ pmc_pair default
 python tools/pmc_traffic.py "$(ls -t $O/pmc_default_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls -t $O/pmc_default_WRITE_SIZE/*/*_counter_collection.csv | head -1)" 5 \
   $O/pmc_traffic.json '{"points": 100000, "scenes": 1, "dtype": "bf16", "kind": "surface"}'
 python tools/pmc_sq.py "$(ls -t $O/pmc_default_sq/*/*_counter_collection.csv | head -1)" 5 $O/pmc_sq.json
+fi
 # ---- BASELINE configs[2]: PTv3 semseg on a 120k-point LiDAR-like scan
+if [[ $PART == *B* ]]; then
 A="--model semseg --kind lidar --points 120000"
 python bench.py $A --cpu-sample 0 --no-extra > $O/lidar_bench.json 2> $O/lidar_bench.err
 rm -rf $O/lidar_stats
@@ -41,6 +47,8 @@ pmc_pair lidar $A
 python tools/pmc_traffic.py "$(ls -t $O/pmc_lidar_FETCH_SIZE/*/*_counter_collection.csv | head -1)" "$(ls -t $O/pmc_lidar_WRITE_SIZE/*/*_counter_collection.csv | head -1)" 5 \
   $O/pmc_traffic_lidar.json '{"points": 120000, "scenes": 1, "dtype": "bf16", "kind": "lidar", "model": "semseg"}'
 python tools/pmc_sq.py "$(ls -t $O/pmc_lidar_sq/*/*_counter_collection.csv | head -1)" 5 $O/pmc_sq_lidar.json
+fi
+if [[ $PART == *C* ]]; then
 # ---- the training step: bench line with its roofline + kernel stats of the same command
 python bench.py --mode train --steps 10 --warmup 3 2>/dev/null | grep '^{"metric"' > $O/bench_n1_train.json
 cut -c1-220 $O/bench_n1_train.json
@@ -56,3 +64,4 @@ rm -rf $O/swin_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/swin_stats -- python tools/bench_swin.py 1000000 model > $O/swin1m.log 2>&1
 cp "$(ls -t $O/swin_stats/*/*_kernel_stats.csv | head -1)" $O/swin1m_kernel_stats.csv; rm -rf $O/swin_stats
 tail -1 $O/swin1m.log
+fi

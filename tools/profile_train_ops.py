@@ -32,7 +32,13 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU], with_stack=True) as prof:
+    cfg = None
+    try:
+        cfg = torch._C._profiler._ExperimentalConfig(verbose=True)
+    except Exception:
+        pass
+    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU], with_stack=True,
+                                experimental_config=cfg) as prof:
         step()
     torch.cuda.synchronize()
     launching = ("aten::fill_", "aten::zero_", "aten::mul", "aten::mul_", "aten::add", "aten::add_", "aten::copy_",
@@ -43,9 +49,15 @@ def main():
     by_site = Counter()
     for ev in prof.events():
         if ev.name in launching:
-            site = next((f for f in ev.stack if "pointcept-keypointdetection_amd" in f or "ptv3_hip" in f), "?")
-            by_site[(ev.name, site.split("pointcept-keypointdetection_amd/")[-1][:90])] += 1
-    for (name, site), n in by_site.most_common(45):
+            site = next((f for f in ev.stack if "ptv3_hip/" in f or "pointcept/" in f or "bench.py" in f), None)
+            if site is None:   # an autograd node without Python frames: name the node that issued it
+                par = ev.cpu_parent
+                while par is not None and par.cpu_parent is not None and not par.name.startswith(("autograd::", "torch::autograd", "Optimizer")) \
+                        and "Backward" not in par.name:
+                    par = par.cpu_parent
+                site = "<" + (par.name if par is not None else "?") + ">"
+            by_site[(ev.name, site.split("pointcept-keypointdetection_amd/")[-1][:110])] += 1
+    for (name, site), n in by_site.most_common(70):
         print(f"{n:5d}  {name:22s} {site}")
 
 
