@@ -14,4 +14,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace ptv3
 
 extern "C" const char* ptv3_last_error(void) { return ptv3::g_err; }
-extern "C" int ptv3_version(void) { return 210; }
+extern "C" int ptv3_version(void) { return 300; }
