@@ -144,7 +144,7 @@ struct TnArgs {
 // (an even stride cannot do better: the stores are 8-byte pieces of rows 4 channels apart).
 constexpr int TN_RB_MAX = 128;
 template <typename T, int RB, int LS>
-__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
+__device__ __forceinline__ void gemm_tn_body(const TnArgs& a, const int bx, const int by, const int bz) {
   typedef typename Vec4<T>::type V4;
   constexpr int NJ = RB / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char tn_smem[];
@@ -155,11 +155,11 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
-  const int to = blockIdx.x / a.tiles_c, tc = blockIdx.x % a.tiles_c;
+  const int to = bx / a.tiles_c, tc = bx % a.tiles_c;
   const int o0 = 64 * to, c0 = 64 * tc;
   const int ncols = a.packed ? a.kvol * a.cin : a.cin;   // column space of this launch's tiles
   const int nto = (min(64, a.cout - o0) + 15) / 16, ntc = (min(64, ncols - c0) + 15) / 16;
-  const int64_t r0 = (int64_t)blockIdx.z * a.rows_per_chunk;
+  const int64_t r0 = (int64_t)bz * a.rows_per_chunk;
   const int64_t r1 = r0 + a.rows_per_chunk < a.m ? r0 + a.rows_per_chunk : a.m;
   f32x4 acc[4][4];
 #pragma unroll
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   // transposes them in registers and stores 4 x (4 consecutive rows of one channel) per patch
   const int rg = threadIdx.x >> 4, cg = threadIdx.x & 15;
   const int mycol = c0 + 4 * cg;                                   // this thread's 4 columns of the gathered operand
-  const int tap = a.packed ? mycol / a.cin : (int)blockIdx.y;      // packed: a tile spans 64 / cin taps
+  const int tap = a.packed ? mycol / a.cin : by;      // packed: a tile spans 64 / cin taps
   const int mych = a.packed ? mycol % a.cin : mycol;
   const bool oka = o0 + 4 * cg < a.cout, okb = mycol < ncols;
   V4 ra[NJ][4], rb[NJ][4];
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
   };
   // bias gradient (column sums of dy) as a by-product of the staging: this thread sees channels o0 + 4cg .. +3 of
   // every row block; only the workgroups of the first input-channel tile / first tap keep them
-  const bool want_b = a.dbias != nullptr && tc == 0 && (a.packed || blockIdx.y == 0);
+  const bool want_b = a.dbias != nullptr && tc == 0 && (a.packed || by == 0);
   float bs[4] = {0.f, 0.f, 0.f, 0.f};
   fetch(r0);
   for (int64_t rblk = r0; rblk < r1; rblk += RB) {
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += sR[r * 64 + threadIdx.x];
-      a.dbias[(int64_t)blockIdx.z * a.slab_stride + o0 + threadIdx.x] = t;
+      a.dbias[(int64_t)bz * a.slab_stride + o0 + threadIdx.x] = t;
     }
     __syncthreads();
   }
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
     __syncthreads();
   }
   if (wave != 0) return;
-  float* out = a.out + (int64_t)blockIdx.z * a.slab_stride;
+  float* out = a.out + (int64_t)bz * a.slab_stride;
   const int64_t ld = (int64_t)a.kvol * a.cin;
 #pragma unroll
   for (int p = 0; p < 4; ++p)
@@ -300,8 +300,29 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int o = o0 + 16 * p + 4 * g + r, c = c0 + 16 * q + i;
-          if (o < a.cout && c < ncols) out[o * ld + (a.packed ? 0 : (int64_t)blockIdx.y * a.cin) + c] = acc[p][q][r];
+          if (o < a.cout && c < ncols) out[o * ld + (a.packed ? 0 : (int64_t)by * a.cin) + c] = acc[p][q][r];
         }
+}
+
+template <typename T, int RB, int LS>
+__global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
+  gemm_tn_body<T, RB, LS>(a, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// Several dense weight gradients as ONE launch (the five linears of a block: their operands are all alive at the end of
+// the block's backward).  At the deep levels a single gradient is 64 - 400 workgroups of a few rounds each, a launch that
+// lasts as long as one workgroup; together they fill the chip.  Workgroup -> (problem, tile, row chunk); every problem
+// keeps its own chunking and slabs, so the results are bitwise those of separate launches.
+constexpr int TN_GROUP = 8;
+struct TnGroup { TnArgs v[TN_GROUP]; int first[TN_GROUP]; int tiles[TN_GROUP]; };
+template <typename T, int RB, int LS>
+__global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup grp, int count) {
+  int k = 0;
+#pragma unroll 1
+  for (int t = 1; t < count; ++t)
+    if (grp.first[t] <= (int)blockIdx.x) k = t;
+  const int local = (int)blockIdx.x - grp.first[k];
+  gemm_tn_body<T, RB, LS>(grp.v[k], local % grp.tiles[k], 0, local / grp.tiles[k]);
 }
 
 static bool tn_packed(int cin, int kvol) { return kvol > 1 && cin < 64 && 64 % cin == 0; }
@@ -652,6 +673,43 @@ __global__ void __launch_bounds__(256) segment_bwd_kernel(const T* __restrict__ 
 
 }  // namespace ptv3
 
+namespace ptv3 {
+struct TnQueue {
+  TnGroup grp; int count, blocks, dtype; double flops, bytes;
+  int ns[TN_GROUP]; int64_t nw[TN_GROUP]; float* dw[TN_GROUP]; float* db[TN_GROUP]; float* ws[TN_GROUP];
+};
+static thread_local TnQueue* g_tn_defer = nullptr;
+size_t tn_defer_storage_bytes() { return sizeof(TnQueue); }
+void tn_defer_begin(void* storage) {   // storage: tn_defer_storage_bytes() owned by the caller; NULL ends deferral
+  g_tn_defer = (TnQueue*)storage;
+  if (g_tn_defer) { g_tn_defer->count = 0; g_tn_defer->blocks = 0; g_tn_defer->flops = g_tn_defer->bytes = 0.0; }
+}
+int tn_defer_flush(hipStream_t s) {
+  TnQueue* q = g_tn_defer;
+  if (!q || q->count == 0) return PTV3_OK;
+  static int rbsel = -1;
+  if (rbsel < 0) { const char* e = getenv("PTV3_TN_RB"); rbsel = e ? atoi(e) : 64; }
+  const int prof = prof_begin(s, PROF_BACKWARD, q->flops, q->bytes, nullptr, 0, 0.0);
+  prof_kernel(prof, PK_GEMM_TN);
+#define TNG_LAUNCH(T, RB, LS)                                                                                       \
+  hipLaunchKernelGGL((gemm_tn_group_kernel<T, RB, LS>), dim3((unsigned)q->blocks), dim3(256), 2 * 64 * (LS) * sizeof(T), s, \
+                     q->grp, q->count)
+  if (q->dtype == PTV3_F32) TNG_LAUNCH(float, 64, 68);
+  else if (rbsel == 128) TNG_LAUNCH(__bf16, 128, 196);
+  else TNG_LAUNCH(__bf16, 64, 68);
+#undef TNG_LAUNCH
+  prof_end(prof, s);
+  for (int k = 0; k < q->count; ++k)
+    if (q->ns[k] > 1) {
+      const int cout = q->grp.v[k].cout;
+      if (q->db[k]) slab_sum(q->ws[k], q->ns[k], q->nw[k] + cout, q->dw[k], s, q->nw[k], q->db[k]);
+      else slab_sum(q->ws[k], q->ns[k], q->nw[k], q->dw[k], s);
+    }
+  q->count = 0; q->blocks = 0; q->flops = q->bytes = 0.0;
+  return hipGetLastError() == hipSuccess ? PTV3_OK : PTV3_ERR_LAUNCH;
+}
+}  // namespace ptv3
+
 using namespace ptv3;
 
 #define BWD_DTYPE_CHECK(name) PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, name ": bad dtype %d", dtype)
@@ -689,6 +747,21 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
   a.packed = tn_packed(cin, kvol) ? 1 : 0;
   a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)(a.packed ? cdiv((int64_t)kvol * cin, 64) : cdiv(cin, 64));
   dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)(a.packed ? 1 : kvol), (unsigned)ns);
+  if (g_tn_defer && kvol == 1) {   // queued: runs in tn_defer_flush() together with the other linears of the block
+    if (g_tn_defer->count == TN_GROUP) { const int rc = tn_defer_flush(s); if (rc != PTV3_OK) return rc; }
+    TnQueue& q = *g_tn_defer;
+    if (q.count == 0) q.dtype = dtype;
+    PTV3_REQUIRE(q.dtype == dtype, "gemm_tn: one dtype per deferred group");
+    q.grp.v[q.count] = a;
+    q.grp.first[q.count] = q.blocks;
+    q.grp.tiles[q.count] = (int)grid.x;
+    q.blocks += (int)(grid.x * grid.z);
+    q.flops += 2.0 * m * cout * (double)cin;
+    q.bytes += ((double)m * (cout + cin)) * (dtype == PTV3_F32 ? 4 : 2) + (double)ns * nw * 4.0;
+    q.ns[q.count] = (int)ns; q.nw[q.count] = nw; q.dw[q.count] = dw; q.db[q.count] = dbias; q.ws[q.count] = (float*)workspace;
+    ++q.count;
+    return PTV3_OK;
+  }
   // LDS: two [64][LS] operand blocks; the 64 x 64 fp32 cross-wave reduction reuses them after the last block
   static int rbsel = -1;
   if (rbsel < 0) { const char* e = getenv("PTV3_TN_RB"); rbsel = e ? atoi(e) : 64; }

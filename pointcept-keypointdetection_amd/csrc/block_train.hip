@@ -18,6 +18,11 @@ namespace ptv3 {
 void slab_defer_begin(void* storage);
 int slab_defer_flush(hipStream_t s);
 size_t slab_defer_storage_bytes();
+// deferred dense weight gradients (backward.hip): the ptv3_gemm_tn calls with kvol = 1 between begin and flush run as
+// one grouped launch; their operands must stay alive until the flush
+void tn_defer_begin(void* storage);
+int tn_defer_flush(hipStream_t s);
+size_t tn_defer_storage_bytes();
 
 // out[i][:] = (skip ? skip[i][:] : 0) + f[i] * x[i][:], f[i] = u[i] < keep ? 1 / keep : 0: timm's DropPath on an (N, C)
 // matrix (a Bernoulli(keep) factor per point, scaled by 1 / keep) from a uniform draw u; fp32 fma, one rounding
@@ -53,6 +58,7 @@ static int rowscale_add(const void* x, const float* u, float keep, const void* s
 }
 
 struct SlabSegsStorage { alignas(16) unsigned char bytes[1024]; };   // >= slab_defer_storage_bytes(), checked at use
+struct TnQueueStorage { alignas(16) unsigned char bytes[2048]; };    // >= tn_defer_storage_bytes(), checked at use
 
 struct Bump {   // 256-byte aligned carving of the caller's workspace
   char* base; size_t size, at;
@@ -211,7 +217,13 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   // as one launch at the end: each producer gets slab memory of its own
   SlabSegsStorage segs;
   slab_defer_begin(&segs);
-  struct EndDefer { ~EndDefer() { slab_defer_begin(nullptr); } } end_defer;
+  // the five dense weight gradients wait for the end of the block as well (dmp, dh, dpp, dqkv, dc2 and their inputs stay
+  // where they are until then) and run as one grouped launch: PTV3_TN_GROUP=0 launches them one by one
+  static const bool tn_group = [] { const char* e = getenv("PTV3_TN_GROUP"); return !(e && atoi(e) == 0); }();
+  TnQueueStorage tnq;
+  PTV3_REQUIRE(tn_defer_storage_bytes() <= sizeof(TnQueueStorage), "block_train_bwd: weight-gradient queue storage");
+  if (tn_group) tn_defer_begin(&tnq);
+  struct EndDefer { ~EndDefer() { slab_defer_begin(nullptr); tn_defer_begin(nullptr); } } end_defer;
   auto own = [&](size_t bytes, size_t* got) { *got = bytes; return ws.take(bytes); };
 #define GEMM_TN(dy, x, dw, db, cout, cin)                                                            \
   do {                                                                                               \
@@ -265,6 +277,7 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
     PTV3_REQUIRE(w != nullptr, "block_train_bwd: workspace too small");
     TRY(ptv3_gemm_tn(dc1, xin, b->nbr, b->dw_conv, b->db_conv, n, c, c, b->kvol, dt, w, wb, s));
   }
+  TRY(tn_defer_flush(s));
   TRY(slab_defer_flush(s));
 #undef GEMM
 #undef GEMM_TN
