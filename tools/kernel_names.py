@@ -19,6 +19,8 @@ def label(name):
                                               "gather (sparse conv)" if m.group(3) == "1" else "dense")
     if "gemm_kernel<bool _Accum" in n:   # rocprofv3's demangler on gemm_kernel<__bf16, 2, ...>: the 32-channel tile
         return "gemm_kernel<bf16,32ch>"
+    if "gemm_tn_group_kernel" in n:
+        return "gemm_tn_group_kernel"
     m = re.search(r"(rows_linear|block_head_wide|block_tail_wide|block_head_coop|block_tail_coop|block_head|block_tail|mlp2|layernorm|splitk_reduce|pool_feat|"
                   r"gemm_tn|attn_bwd_dq|attn_bwd_dkv)_kernel", n)
     if m:
