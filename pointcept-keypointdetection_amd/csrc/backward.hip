@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) gemm_tn_kernel(TnArgs a) {
 // lasts as long as one workgroup; together they fill the chip.  Workgroup -> (problem, tile, row chunk); every problem
 // keeps its own chunking and slabs, so the results are bitwise those of separate launches.
 constexpr int TN_GROUP = 8;
-struct TnGroup { TnArgs v[TN_GROUP]; int first[TN_GROUP]; int tiles[TN_GROUP]; };
+struct TnGroup { TnArgs v[TN_GROUP]; int first[TN_GROUP]; int tiles[TN_GROUP]; int taps[TN_GROUP]; };
 template <typename T, int RB, int LS>
 __global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup grp, int count) {
   int k = 0;
@@ -322,7 +322,8 @@ __global__ void __launch_bounds__(256) gemm_tn_group_kernel(TnGroup grp, int cou
   for (int t = 1; t < count; ++t)
     if (grp.first[t] <= (int)blockIdx.x) k = t;
   const int local = (int)blockIdx.x - grp.first[k];
-  gemm_tn_body<T, RB, LS>(grp.v[k], local % grp.tiles[k], 0, local / grp.tiles[k]);
+  const int tt = grp.tiles[k] * grp.taps[k];     // taps: grid.y of a convolution's separate launch (1 for a linear)
+  gemm_tn_body<T, RB, LS>(grp.v[k], local % grp.tiles[k], (local % tt) / grp.tiles[k], local / tt);
 }
 
 static bool tn_packed(int cin, int kvol) { return kvol > 1 && cin < 64 && 64 % cin == 0; }
@@ -676,20 +677,22 @@ __global__ void __launch_bounds__(256) segment_bwd_kernel(const T* __restrict__ 
 namespace ptv3 {
 struct TnQueue {
   TnGroup grp; int count, blocks, dtype; double flops, bytes;
+  const int32_t* prof_nbr; int64_t prof_pairs; double prof_pair_flops;   // the group's convolution: flops by active pairs
   int ns[TN_GROUP]; int64_t nw[TN_GROUP]; float* dw[TN_GROUP]; float* db[TN_GROUP]; float* ws[TN_GROUP];
 };
 static thread_local TnQueue* g_tn_defer = nullptr;
 size_t tn_defer_storage_bytes() { return sizeof(TnQueue); }
 void tn_defer_begin(void* storage) {   // storage: tn_defer_storage_bytes() owned by the caller; NULL ends deferral
   g_tn_defer = (TnQueue*)storage;
-  if (g_tn_defer) { g_tn_defer->count = 0; g_tn_defer->blocks = 0; g_tn_defer->flops = g_tn_defer->bytes = 0.0; }
+  if (g_tn_defer) { g_tn_defer->count = 0; g_tn_defer->blocks = 0; g_tn_defer->flops = g_tn_defer->bytes = 0.0; g_tn_defer->prof_nbr = nullptr; }
 }
 int tn_defer_flush(hipStream_t s) {
   TnQueue* q = g_tn_defer;
   if (!q || q->count == 0) return PTV3_OK;
   static int rbsel = -1;
   if (rbsel < 0) { const char* e = getenv("PTV3_TN_RB"); rbsel = e ? atoi(e) : 64; }
-  const int prof = prof_begin(s, PROF_BACKWARD, q->flops, q->bytes, nullptr, 0, 0.0);
+  const int prof = prof_begin(s, PROF_BACKWARD, q->flops, q->bytes, q->prof_nbr, q->prof_nbr ? q->prof_pairs : 0,
+                              q->prof_nbr ? q->prof_pair_flops : 0.0);
   prof_kernel(prof, PK_GEMM_TN);
 #define TNG_LAUNCH(T, RB, LS)                                                                                       \
   hipLaunchKernelGGL((gemm_tn_group_kernel<T, RB, LS>), dim3((unsigned)q->blocks), dim3(256), 2 * 64 * (LS) * sizeof(T), s, \
@@ -705,7 +708,7 @@ int tn_defer_flush(hipStream_t s) {
       if (q->db[k]) slab_sum(q->ws[k], q->ns[k], q->nw[k] + cout, q->dw[k], s, q->nw[k], q->db[k]);
       else slab_sum(q->ws[k], q->ns[k], q->nw[k], q->dw[k], s);
     }
-  q->count = 0; q->blocks = 0; q->flops = q->bytes = 0.0;
+  q->count = 0; q->blocks = 0; q->flops = q->bytes = 0.0; q->prof_nbr = nullptr;
   return hipGetLastError() == hipSuccess ? PTV3_OK : PTV3_ERR_LAUNCH;
 }
 }  // namespace ptv3
@@ -747,7 +750,7 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
   a.packed = tn_packed(cin, kvol) ? 1 : 0;
   a.cout = cout; a.cin = cin; a.kvol = kvol; a.tiles_c = (int)(a.packed ? cdiv((int64_t)kvol * cin, 64) : cdiv(cin, 64));
   dim3 grid((unsigned)(cdiv(cout, 64) * a.tiles_c), (unsigned)(a.packed ? 1 : kvol), (unsigned)ns);
-  if (g_tn_defer && kvol == 1) {   // queued: runs in tn_defer_flush() together with the other linears of the block
+  if (g_tn_defer) {   // queued: runs in tn_defer_flush() together with the other weight gradients of the block
     if (g_tn_defer->count == TN_GROUP) { const int rc = tn_defer_flush(s); if (rc != PTV3_OK) return rc; }
     TnQueue& q = *g_tn_defer;
     if (q.count == 0) q.dtype = dtype;
@@ -755,8 +758,10 @@ extern "C" int ptv3_gemm_tn(const void* dy, const void* x, const int32_t* nbr, f
     q.grp.v[q.count] = a;
     q.grp.first[q.count] = q.blocks;
     q.grp.tiles[q.count] = (int)grid.x;
-    q.blocks += (int)(grid.x * grid.z);
-    q.flops += 2.0 * m * cout * (double)cin;
+    q.grp.taps[q.count] = (int)grid.y;
+    q.blocks += (int)(grid.x * grid.y * grid.z);
+    if (nbr && !q.prof_nbr) { q.prof_nbr = nbr; q.prof_pairs = m * kvol; q.prof_pair_flops = 2.0 * cin * cout; }
+    else q.flops += 2.0 * m * cout * (double)cin * kvol;   // (a second convolution of a group would count dense)
     q.bytes += ((double)m * (cout + cin)) * (dtype == PTV3_F32 ? 4 : 2) + (double)ns * nw * 4.0;
     q.ns[q.count] = (int)ns; q.nw[q.count] = nw; q.dw[q.count] = dw; q.db[q.count] = dbias; q.ws[q.count] = (float*)workspace;
     ++q.count;

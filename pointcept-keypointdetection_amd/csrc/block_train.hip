@@ -18,8 +18,7 @@ namespace ptv3 {
 void slab_defer_begin(void* storage);
 int slab_defer_flush(hipStream_t s);
 size_t slab_defer_storage_bytes();
-// deferred dense weight gradients (backward.hip): the ptv3_gemm_tn calls with kvol = 1 between begin and flush run as
-// one grouped launch; their operands must stay alive until the flush
+// deferred weight gradients (backward.hip): the ptv3_gemm_tn calls between begin and flush run as one grouped launch; their operands must stay alive until the flush
 void tn_defer_begin(void* storage);
 int tn_defer_flush(hipStream_t s);
 size_t tn_defer_storage_bytes();
@@ -217,7 +216,7 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   // as one launch at the end: each producer gets slab memory of its own
   SlabSegsStorage segs;
   slab_defer_begin(&segs);
-  // the five dense weight gradients wait for the end of the block as well (dmp, dh, dpp, dqkv, dc2 and their inputs stay
+  // the six weight gradients wait for the end of the block as well (dmp, dh, dpp, dqkv, dc2, dc1 and their inputs stay
   // where they are until then) and run as one grouped launch: PTV3_TN_GROUP=0 launches them one by one
   static const bool tn_group = [] { const char* e = getenv("PTV3_TN_GROUP"); return !(e && atoi(e) == 0); }();
   TnQueueStorage tnq;
