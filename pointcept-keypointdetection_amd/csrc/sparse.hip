@@ -1,6 +1,7 @@
 // Active-site hash table and neighbour table ("rulebook") for the submanifold convolutions.
 // Replaces spconv's indice-pair generation (called lazily per indice_key by SubMConv3d in
 // point_transformer_v3m1_base.py:277-284,499-506 on the tensor built in structure.py:111-146).
+#include <stdlib.h>
 #include "common.h"
 #include "hashtable.h"
 #include "../../include/ptv3_hip.h"
@@ -51,6 +52,39 @@ __global__ void ht_neighbors_kernel(const int32_t* __restrict__ idx, int64_t n,
   nbr[t] = found;
 }
 
+// The neighbour relation of a submanifold convolution is symmetric: j = nbr[i][d]  <=>  i = nbr[j][kvol - 1 - d] (the
+// mirrored offset).  Half the taps are probed; a hit fills both entries, the table is pre-filled with -1.  125 probes per
+// site at the 5^3 stem are the longest item in front of a forward's first feature kernel (133 us at 100k sites).
+__global__ void ht_neighbors_half_kernel(const int32_t* __restrict__ idx, int64_t n,
+                                         const unsigned long long* __restrict__ keys, const int32_t* __restrict__ vals,
+                                         uint64_t mask, int ksize, int kvol, int slots_log2,
+                                         int32_t* __restrict__ nbr) {
+  // a workgroup is 256 >> slots_log2 sites x 2^slots_log2 tap slots (>= kvol / 2 + 1): site and tap by shifts - the
+  // flat index of the full-probing kernel costs a 64-bit division per thread, more than its probe
+  const int hv = kvol / 2 + 1;
+  const int64_t i = (int64_t)blockIdx.x * (256 >> slots_log2) + (threadIdx.x >> slots_log2);
+  const int d = threadIdx.x & ((1 << slots_log2) - 1);
+  if (i >= n || d >= hv) return;
+  if (d == kvol / 2) { nbr[i * kvol + d] = (int32_t)i; return; }   // the centre tap is the site itself
+  int c = d % ksize, b_ = (d / ksize) % ksize, a = d / (ksize * ksize);
+  int half = ksize / 2;
+  int x = idx[4 * i + 1] + a - half, y = idx[4 * i + 2] + b_ - half, z = idx[4 * i + 3] + c - half;
+  if (!(x >= 0 && y >= 0 && z >= 0 && x < 65536 && y < 65536 && z < 65536)) return;
+  uint64_t key = site_key(idx[4 * i], x, y, z);
+  uint64_t slot = mix64(key) & mask;
+  for (uint64_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long kq = keys[slot];
+    if (kq == key) {
+      const int32_t j = vals[slot];
+      nbr[i * kvol + d] = j;
+      nbr[(int64_t)j * kvol + (kvol - 1 - d)] = (int32_t)i;
+      return;
+    }
+    if (kq == HT_EMPTY) return;
+    slot = (slot + 1) & mask;
+  }
+}
+
 }  // namespace ptv3
 
 using namespace ptv3;
@@ -89,8 +123,20 @@ extern "C" int ptv3_subm_neighbors(const int32_t* indices, int64_t n, const void
   const int kvol = ksize * ksize * ksize;
   const unsigned long long* keys = (const unsigned long long*)table;
   const int32_t* vals = (const int32_t*)((const char*)table + slots * 8);
-  hipLaunchKernelGGL(ht_neighbors_kernel, dim3((unsigned)cdiv(n * kvol, 256)), dim3(256), 0,
-                     (hipStream_t)stream, indices, n, keys, vals, (uint64_t)(slots - 1), ksize, kvol, nbr);
+  const char* sym = getenv("PTV3_NBR_SYMMETRIC");      // 0: every tap probed (the checker of the symmetric fill)
+  if (sym && atoi(sym) == 0) {
+    hipLaunchKernelGGL(ht_neighbors_kernel, dim3((unsigned)cdiv(n * kvol, 256)), dim3(256), 0,
+                       (hipStream_t)stream, indices, n, keys, vals, (uint64_t)(slots - 1), ksize, kvol, nbr);
+  } else {
+    if (hipMemsetAsync(nbr, 0xFF, (size_t)n * kvol * sizeof(int32_t), (hipStream_t)stream) != hipSuccess) {
+      set_error("subm_neighbors: memset failed");
+      return PTV3_ERR_LAUNCH;
+    }
+    int sl = 0;
+    while ((1 << sl) < kvol / 2 + 1) ++sl;          // 1: 0, 3^3: 4, 5^3: 6, 7^3: 8
+    hipLaunchKernelGGL(ht_neighbors_half_kernel, dim3((unsigned)cdiv(n, 256 >> sl)), dim3(256), 0,
+                       (hipStream_t)stream, indices, n, keys, vals, (uint64_t)(slots - 1), ksize, kvol, sl, nbr);
+  }
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }

@@ -269,6 +269,32 @@ def test_linear_bf16(dev, m):
     assert (out.float().cpu() - ref).abs().max().item() < 5e-2
 
 
+@pytest.mark.parametrize("n,k,extent", [(20000, 5, 96), (20000, 3, 64), (5000, 7, 40), (1, 3, 8), (300, 5, 7)])
+def test_subm_neighbors_symmetric_fill_equals_full_probing(dev, n, k, extent):
+    """ptv3_subm_neighbors probes half the taps and fills j = nbr[i][d] and i = nbr[j][kvol-1-d] from one hit (the
+    relation of a submanifold conv is symmetric); PTV3_NBR_SYMMETRIC=0 probes every tap.  Whole tables, bitwise - two
+    scenes in the batch, sites at the coordinate origin (taps at negative coordinates) and a dense little cube."""
+    import os
+    from ptv3_hip import ops
+    import ptv3_scenes as S
+    if n > 1:
+        data = S.make_batch([n - n // 3, n // 3], in_channels=4, extent=extent, seed=n + k)
+        off = data["offset"]
+        batch = torch.repeat_interleave(torch.arange(2), torch.diff(off, prepend=torch.zeros(1, dtype=torch.long)))
+        idx = torch.cat([batch[:, None].int(), data["grid_coord"].int()], 1).contiguous()
+    else:
+        idx = torch.zeros(1, 4, dtype=torch.int32)
+    idx = idx.to(dev)
+    half, _ = ops.subm_neighbors(idx, k)
+    os.environ["PTV3_NBR_SYMMETRIC"] = "0"
+    try:
+        full, _ = ops.subm_neighbors(idx, k)
+    finally:
+        os.environ.pop("PTV3_NBR_SYMMETRIC", None)
+    assert torch.equal(half, full)
+    assert (half[:, k ** 3 // 2].cpu() == torch.arange(idx.shape[0])).all()
+
+
 @pytest.mark.parametrize("n,cin,cout,k", [(3000, 4, 32, 5), (2500, 32, 32, 3), (1200, 64, 64, 3), (700, 8, 16, 3)])
 def test_subm_conv_vs_oracle(dev, n, cin, cout, k):
     from ptv3_hip import ops
