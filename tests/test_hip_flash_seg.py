@@ -132,6 +132,51 @@ def test_flash_attention_backward_vs_autograd(dev, dtype):
     assert (dq - q.grad).abs().max().item() < tol * gscale, ((dq - q.grad).abs().max().item(), gscale)
 
 
+def test_flash_attention_dropout_ragged_windows_vs_autograd_with_the_same_mask(dev):
+    """dropout_p of the flash call (v3m1_base.py:211) on ragged windows: ptv3_window_attn_drop_fwd / _bwd with
+    cu_seqlens against torch autograd over softmax * mask / (1 - p) per sequence, the mask rebuilt on the host from the
+    kernels' hash (query slot = padded slot, key = position inside its sequence)."""
+    from ptv3_hip import ops
+    from oracle import sfc
+    gen = torch.Generator().manual_seed(5)
+    C, H, K, p, seed = 64, 4, 128, 0.3, 777
+    off = np.array([300, 390, 518, 519, 800])     # scenes of 300, 90, 128, 1, 281 points
+    n = int(off[-1])
+    pad, unpad, cu = sfc.pad_plan(off, K)
+    order = torch.cat([torch.randperm(b - a, generator=gen) + a for a, b in zip([0] + off[:-1].tolist(), off.tolist())])
+    inverse = torch.empty_like(order)
+    inverse[order] = torch.arange(n)
+    qkv = torch.randn(n, 3 * C, generator=gen)
+    dout = torch.randn(n, C, generator=gen)
+    scale = (C // H) ** -0.5
+    q = qkv.clone().requires_grad_(True)
+    o = order[torch.from_numpy(pad)]
+    inv = torch.from_numpy(unpad)[inverse]
+    x = q[o].reshape(-1, 3, H, C // H)
+    outs = torch.empty(x.shape[0], H, C // H)
+    kept = total = 0
+    for a, b in zip(cu[:-1].tolist(), cu[1:].tolist()):
+        ln = b - a
+        blk = x[a:b].permute(1, 2, 0, 3)                               # (3, H, ln, D)
+        attn = torch.softmax((blk[0] * scale) @ blk[1].transpose(-2, -1), dim=-1)
+        keep = ops.drop_keep_mask(np.arange(a, b)[None, :, None], np.arange(H)[:, None, None],
+                                  np.arange(ln)[None, None, :], H, seed, p)
+        kept += keep.sum(); total += keep.size
+        attn = attn * torch.from_numpy(keep.astype(np.float32)) / (1.0 - float(np.float32(p)))
+        outs[a:b] = (attn @ blk[2]).transpose(0, 1)
+    assert abs(kept / total - (1 - p)) < 0.01
+    ref = outs.reshape(-1, C)[inv]
+    ref.backward(dout)
+    wo, wi = ops.window_maps(order.to(dev), inverse.to(dev), torch.from_numpy(pad).to(dev),
+                             torch.from_numpy(unpad).to(dev))
+    cud = torch.from_numpy(cu).to(dev)
+    qd = qkv.to(dev)
+    out = ops.window_attention_drop(qd, wo, wi, H, K, scale, p, seed, cu_seqlens=cud)
+    dq = ops.window_attention_drop_bwd(qd, out, dout.to(dev), wo, wi, H, K, scale, p, seed, cu_seqlens=cud).cpu()
+    assert (out.cpu() - ref.detach()).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    assert (dq - q.grad).abs().max().item() < 1e-4 * q.grad.abs().max().item()
+
+
 def _offset_model(cfg, hidden_dim=32):
     from pointcept.models import build_model
     return build_model(dict(type="OffsetKeypointPTv3", num_keypoints=6, hidden_dim=hidden_dim,
