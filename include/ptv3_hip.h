@@ -391,6 +391,19 @@ int ptv3_window_attn_varlen_bwd(const void* qkv, const void* out, const void* do
                                 const int32_t* win_inverse, const int32_t* cu_seqlens, int num_windows, void* dqkv,
                                 int64_t n, int64_t n_pad, int c, int heads, int max_seqlen, float scale, int dtype,
                                 void* workspace, size_t workspace_bytes, void* stream);
+/* Training pair of the attention: the forward also leaves the log2-domain log-sum-exp of every (padded slot, head) row
+ * (lse: n_pad x heads floats), the backward takes it instead of recomputing it in its first pass (a third of that pass's
+ * work).  cu_seqlens NULL: uniform windows of `patch` slots, else ragged ones (patch = max_seqlen, sum_len_sq for the flop
+ * count).  Same kernels and results as ptv3_window_attn_fwd / _varlen_fwd; dqkv differs from ptv3_window_attn_bwd's only
+ * by the summation the two log-sum-exps went through.  workspace: ptv3_window_attn_bwd_workspace_bytes. */
+int ptv3_window_attn_train_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                               const int32_t* cu_seqlens, int num_windows, void* out, float* lse, int64_t n,
+                               int64_t n_pad, int c, int heads, int patch, float scale, double sum_len_sq, int dtype,
+                               void* stream);
+int ptv3_window_attn_train_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                               const int32_t* win_order, const int32_t* win_inverse, const int32_t* cu_seqlens,
+                               int num_windows, void* dqkv, int64_t n, int64_t n_pad, int c, int heads, int patch,
+                               float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
 /* Attention dropout in training (reference: nn.Dropout on the attention probabilities,
  * point_transformer_v3m1_base.py:203; flash_attn dropout_p, :211): out_i = sum_j keep_ij softmax(s)_ij v_j / (1 - p).
  * keep_ij is a counter-based hash of (padded query slot, head, key slot in the window) and `seed` (csrc/common.h
@@ -427,7 +440,7 @@ int ptv3_window_attn_rpe_bwd(const void* qkv, const void* out, const void* dout,
  * conv_feat NULL: the xCPE conv reads feat (every block but the first decoder block of a stage).  mask1 / mask2 (n) fp32
  * or NULL: uniform draws u; the per-point DropPath factor of a branch is u[i] < keep ? 1 / keep : 0 (timm drop_path with
  * scale_by_keep on the (N, C) matrix).  cu_seqlens NULL: uniform windows of `patch` slots.
- * fwd writes c1 .. out; bwd reads them plus dout and writes dfeat (and dconv_feat), dw_* (cout, K), db_* (cout),
+ * fwd writes c1 .. out and attn_lse; bwd reads them plus dout and writes dfeat (and dconv_feat), dw_* (cout, K), db_* (cout),
  * dln0/1/2 (2, c) = [dgamma | dbeta] of the three LayerNorms.  workspace: ptv3_block_train_workspace_bytes(). */
 typedef struct ptv3_block_train {
   int64_t n, n_pad;
@@ -448,6 +461,7 @@ typedef struct ptv3_block_train {
   float *dln0, *dln1, *dln2;
   void* workspace;
   size_t workspace_bytes;
+  float* attn_lse;   /* (n_pad, heads) fp32: written by fwd, read by bwd (ptv3_window_attn_train_fwd / _bwd) */
 } ptv3_block_train;
 size_t ptv3_block_train_workspace_bytes(const ptv3_block_train* block, int backward);
 int ptv3_block_train_fwd(const ptv3_block_train* block, void* stream);

@@ -30,6 +30,7 @@ struct AttnBwdArgs {
   const int32_t* grid; const float* table; int pos_bnd; float* dtab_slab;
   // attention dropout (common.h drop_keep): 0 = none; else the forward's threshold, seed and 1 / (1 - p)
   unsigned drop_thr, drop_seed; float drop_scale;
+  const float* lse_in;   // the forward's log2-domain log-sum-exp per (slot, head), or NULL: pass A recomputes it
 };
 
 constexpr int AB_MAX_TAB = 1024;  // 3 * (2 * pos_bnd + 1) entries of one head's table column held in LDS
@@ -142,9 +143,10 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
     return s;  // s[r] = q_i . k_(16kt+4g+r)
   };
 
-  // ---- sweep 1: log-sum-exp of the scaled scores (log2 domain)
+  // ---- sweep 1: log-sum-exp of the scaled scores (log2 domain) - unless the training forward left it
   float m2 = -INFINITY, l = 0.f;
-  for (int ch = 0; ch < nchunks; ++ch) {
+  const bool have_lse = !RPE && a.lse_in != nullptr;
+  for (int ch = 0; ch < (have_lse ? 0 : nchunks); ++ch) {
     const int kc0 = ch * CT;
     load_chunk(kc0, false);
     const int ntile = (min(CT, P - kc0) + 15) / 16;
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(AttnBwdArgs a) {
     if (mn != -INFINITY) l = l * __builtin_amdgcn_exp2f(m2 - mn) + lo * __builtin_amdgcn_exp2f(mo - mn);
     m2 = mn;
   }
-  const float lse2 = m2 + __log2f(l);
+  const float lse2 = have_lse ? a.lse_in[pq * a.heads + h] : m2 + __log2f(l);
 
   // ---- sweep 2: dQ^T[d][q] += K^T[d][key] * dS^T[key][q]
   f32x4 acc[ND];
@@ -448,7 +450,7 @@ static int window_attn_bwd_impl(const void* qkv, const void* out, const void* do
                                 const int32_t* win_inverse, const int32_t* cu, int nwin, void* dqkv, int64_t n,
                                 int64_t n_pad, int c, int heads, int patch, float scale, int dtype, void* workspace,
                                 hipStream_t s, RpeBwd rpe = RpeBwd{nullptr, nullptr, 0, nullptr}, float p_drop = 0.f,
-                                unsigned seed = 0) {
+                                unsigned seed = 0, const float* lse_in = nullptr) {
   const int d = c / heads;
   if (d != 16 && d != 32 && d != 64) {
     set_error("window_attn_bwd: head_dim %d unsupported (16, 32, 64)", d);
@@ -468,6 +470,7 @@ static int window_attn_bwd_impl(const void* qkv, const void* out, const void* do
   a.scale = scale; a.scale_log2e = scale * 1.44269504088896340736f;
   a.drop_thr = p_drop > 0.f ? (unsigned)std::min(4294967295.0, (double)p_drop * 4294967296.0) : 0u;
   a.drop_seed = seed; a.drop_scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  a.lse_in = lse_in;
   if (hipMemsetAsync(dup, 0xFF, (size_t)n * sizeof(int32_t), s) != hipSuccess) return PTV3_ERR_LAUNCH;
   hipLaunchKernelGGL(dup_slot_kernel, dim3((unsigned)cdiv(n_pad, 256)), dim3(256), 0, s, win_order, win_inverse, n_pad, dup);
 #define AB_CASE(T)                                     \
@@ -574,4 +577,22 @@ extern "C" int ptv3_window_attn_drop_bwd(const void* qkv, const void* out, const
   const int nwin = cu_seqlens ? num_windows : (int)(n_pad / patch);
   return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, cu_seqlens, nwin, dqkv, n, n_pad, c, heads, patch,
                               scale, dtype, workspace, (hipStream_t)stream, RpeBwd{nullptr, nullptr, 0, nullptr}, p_drop, seed);
+}
+
+extern "C" int ptv3_window_attn_train_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                                          const int32_t* win_order, const int32_t* win_inverse, const int32_t* cu_seqlens,
+                                          int num_windows, void* dqkv, int64_t n, int64_t n_pad, int c, int heads, int patch,
+                                          float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_train_bwd: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_train_bwd: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(cu_seqlens != nullptr || n_pad % patch == 0, "window_attn_train_bwd: n_pad=%lld is not a multiple of patch=%d",
+               (long long)n_pad, patch);
+  PTV3_REQUIRE(lse != nullptr, "window_attn_train_bwd: the forward's lse is required");
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_train_bwd: bad dtype %d", dtype);
+  PTV3_REQUIRE(workspace_bytes >= ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, heads, dtype),
+               "window_attn_train_bwd: workspace too small");
+  const int nwin = cu_seqlens ? num_windows : (int)(n_pad / patch);
+  return window_attn_bwd_impl(qkv, out, dout, win_order, win_inverse, cu_seqlens, nwin, dqkv, n, n_pad, c, heads, patch,
+                              scale, dtype, workspace, (hipStream_t)stream, RpeBwd{nullptr, nullptr, 0, nullptr}, 0.f, 0,
+                              lse);
 }

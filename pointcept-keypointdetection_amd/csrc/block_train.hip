@@ -150,7 +150,10 @@ extern "C" int ptv3_block_train_fwd(const ptv3_block_train* b, void* stream) {
   TRY(ptv3_layernorm(b->c2, b->g0, b->b0, b->feat, b->f1, b->g1, b->b1, b->t3, n, c, b->eps, dt, s));
   TRY(ptv3_gemm(b->t3, b->w_qkv, b->qkv, n, c, 3 * c, 1, nullptr, nullptr, b->b_qkv, nullptr, nullptr, PTV3_ACT_NONE,
                 nullptr, nullptr, nullptr, dt, scratch, sb, s));
-  if (b->cu_seqlens)
+  if (b->attn_lse)     // the backward takes the log-sum-exp rows from here instead of recomputing them
+    TRY(ptv3_window_attn_train_fwd(b->qkv, b->win_order, b->win_inverse, b->cu_seqlens, b->num_windows, b->a, b->attn_lse,
+                                   n, b->n_pad, c, b->heads, b->patch, b->scale, b->sum_len_sq, dt, s));
+  else if (b->cu_seqlens)
     TRY(ptv3_window_attn_varlen_fwd(b->qkv, b->win_order, b->win_inverse, b->cu_seqlens, b->num_windows, b->a, n,
                                     b->n_pad, c, b->heads, b->patch, b->scale, b->sum_len_sq, dt, s));
   else
@@ -252,7 +255,10 @@ extern "C" int ptv3_block_train_bwd(const ptv3_block_train* b, void* stream) {
   if (b->mask1) { TRY(rowscale_add(df2, b->mask1, b->keep1, nullptr, dp, n, c, dt, s)); dpp = dp; }
   GEMM(dpp, b->wt_proj, da, c, c);
   GEMM_TN(dpp, b->a, b->dw_proj, b->db_proj, c, c);
-  if (b->cu_seqlens)
+  if (b->attn_lse)
+    TRY(ptv3_window_attn_train_bwd(b->qkv, b->a, da, b->attn_lse, b->win_order, b->win_inverse, b->cu_seqlens,
+                                   b->num_windows, dqkv, n, b->n_pad, c, b->heads, b->patch, b->scale, dt, scratch, sb, s));
+  else if (b->cu_seqlens)
     TRY(ptv3_window_attn_varlen_bwd(b->qkv, b->a, da, b->win_order, b->win_inverse, b->cu_seqlens, b->num_windows, dqkv,
                                     n, b->n_pad, c, b->heads, b->patch, b->scale, dt, scratch, sb, s));
   else

@@ -28,7 +28,8 @@ __global__ void __launch_bounds__(WA_THREADS)
 window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
                    const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int Kmax,
                    int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe,
-                   const int32_t* __restrict__ cu, unsigned drop_thr = 0, unsigned drop_seed = 0, float drop_scale = 1.f) {
+                   const int32_t* __restrict__ cu, unsigned drop_thr = 0, unsigned drop_seed = 0, float drop_scale = 1.f,
+                   float* __restrict__ lse_out = nullptr) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
@@ -214,6 +215,8 @@ window_attn_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_or
     lt += __shfl_xor(lt, 16, 64);
     lt += __shfl_xor(lt, 32, 64);
     const float inv = 1.0f / lt;
+    // training: log2-domain log-sum-exp of every slot's row (borrowed duplicates included: the backward walks slots)
+    if (lse_out && g == 0 && qidx[t] < K) lse_out[(wbase + qidx[t]) * H + h] = m[t] + __log2f(lt);
     if (keep[t]) {
       const int row = sOrd[qidx[t]];
 #pragma unroll
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(512)
 window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ win_order,
                         const int32_t* __restrict__ win_inverse, T* __restrict__ out, int C, int H, int Kmax,
                         int Kpad, int nwin, int qsplit, float scale_log2e, const float* __restrict__ rpe,
-                        RpeTable rt, const int32_t* __restrict__ cu) {
+                        RpeTable rt, const int32_t* __restrict__ cu, float* __restrict__ lse_out) {
   typedef typename Vec4<T>::type V4;
   constexpr int D = 16 * ND;
   constexpr int KS = D + 4;
@@ -521,6 +524,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
   for (int t = 0; t < QT; ++t) {
     const float lsum = SUM_MFMA ? lacc[t][0] : lanes_sum_groups(lacc[t][0]);
     const float inv = 1.0f / lsum;
+    if (lse_out && g == 0 && qidx[t] < K) lse_out[(wbase + qidx[t]) * H + h] = __log2f(lsum) - negm[t][0];   // training
     if (keep[t]) {
       const int row = sOrd[qidx[t]];
 #pragma unroll
@@ -541,7 +545,7 @@ window_attn_full_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ w
 // (cycles on the busiest CU) over the candidates; PTV3_ATTN_WAVES / PTV3_ATTN_QT force a choice for experiments.
 template <typename T> struct FullArgs {
   const T* qkv; const int32_t* wo; const int32_t* wi; T* out; int C, H, K, Kpad, nwin; float scale_log2e;
-  const float* rpe; RpeTable rt; int waves; size_t lds; hipStream_t s; const int32_t* cu;
+  const float* rpe; RpeTable rt; int waves; size_t lds; hipStream_t s; const int32_t* cu; float* lse;
 };
 
 template <typename T, int ND, int RPE, int QT>
@@ -551,7 +555,7 @@ static void launch_full(const FullArgs<T>& a) {
   const int qsplit = (a.K + QB - 1) / QB;
   const unsigned nwg = (unsigned)a.nwin * a.H * qsplit;
   hipLaunchKernelGGL((window_attn_full_kernel<T, ND, RPE, QT>), dim3(nwg), dim3(a.waves * 64), a.lds, a.s, a.qkv, a.wo,
-                     a.wi, a.out, a.C, a.H, a.K, a.Kpad, a.nwin, qsplit, a.scale_log2e, a.rpe, a.rt, a.cu);
+                     a.wi, a.out, a.C, a.H, a.K, a.Kpad, a.nwin, qsplit, a.scale_log2e, a.rpe, a.rt, a.cu, a.lse);
 }
 
 template <typename T, int ND, int QT>
@@ -602,7 +606,8 @@ static bool g_last_launch_tiled = false;   // which kernel the last launch_windo
 template <typename T, int ND>
 static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t* wi, void* out, int C, int H,
                               int K, int nwin, float scale, const float* rpe, hipStream_t s,
-                              RpeTable rt = RpeTable{nullptr, nullptr, 0}, const int32_t* cu = nullptr) {
+                              RpeTable rt = RpeTable{nullptr, nullptr, 0}, const int32_t* cu = nullptr,
+                              float* lse = nullptr) {
   constexpr int D = 16 * ND;
   constexpr int QT = WaCfg<T, ND>::QT;
   const int Kpad = (K + WA_KT - 1) / WA_KT * WA_KT;
@@ -617,7 +622,7 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
     int waves, qt;
     full_config(nwin * (int64_t)H, K, WaCfg<T, ND>::QT, lds_full, &waves, &qt);
     const FullArgs<T> a{(const T*)qkv, wo, wi, (T*)out, C, H, K, Kpad, nwin, scale * 1.44269504088896340736f, rpe,
-                        rt, waves, lds_full, s, cu};
+                        rt, waves, lds_full, s, cu, lse};
     const int rpe_mode = rt.table ? 2 : (rpe ? 1 : 0);
     constexpr int QTMAX = WaCfg<T, ND>::QT;
     if (qt >= 4 && QTMAX >= 4) launch_full_rpe<T, ND, (QTMAX >= 4 ? 4 : QTMAX)>(a, rpe_mode);
@@ -631,7 +636,7 @@ static int launch_window_attn(const void* qkv, const int32_t* wo, const int32_t*
   const size_t lds = (size_t)(WA_KT * (D + 4) + D * (WA_KT + 4)) * sizeof(T) + (size_t)K * 4;
   const unsigned nwg = (unsigned)nwin * H * qsplit;
   hipLaunchKernelGGL((window_attn_kernel<T, ND>), dim3(nwg), dim3(WA_THREADS), lds, s, (const T*)qkv, wo, wi,
-                     (T*)out, C, H, K, nwin, qsplit, scale * 1.44269504088896340736f, rpe, cu);
+                     (T*)out, C, H, K, nwin, qsplit, scale * 1.44269504088896340736f, rpe, cu, 0u, 0u, 1.f, lse);
   PTV3_LAUNCH_CHECK();
   return PTV3_OK;
 }
@@ -698,7 +703,8 @@ extern "C" int ptv3_window_attn_drop_fwd(const void* qkv, const int32_t* win_ord
 
 static int window_attn_fwd_impl(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
                                 const int32_t* cu, int nwin, void* out, int64_t n, int64_t n_pad, int c, int heads,
-                                int patch, float scale, const float* rpe_bias, int dtype, double flops, hipStream_t s) {
+                                int patch, float scale, const float* rpe_bias, int dtype, double flops, hipStream_t s,
+                                float* lse = nullptr) {
   const int d = c / heads;
   if (n == 0) return PTV3_OK;
   if (d != 16 && d != 32 && d != 64) {
@@ -713,9 +719,9 @@ static int window_attn_fwd_impl(const void* qkv, const int32_t* win_order, const
   const RpeTable none{nullptr, nullptr, 0};
 #define WA_CASE(T)                                                                                          \
   switch (d) {                                                                                              \
-    case 16: rc = launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu); break; \
-    case 32: rc = launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu); break; \
-    case 64: rc = launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu); break; \
+    case 16: rc = launch_window_attn<T, 1>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu, lse); break; \
+    case 32: rc = launch_window_attn<T, 2>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu, lse); break; \
+    case 64: rc = launch_window_attn<T, 4>(qkv, win_order, win_inverse, out, c, heads, patch, nwin, scale, rpe_bias, s, none, cu, lse); break; \
     default: break;                                                                                         \
   }
   if (dtype == PTV3_F32) { WA_CASE(float) } else { WA_CASE(__bf16) }
@@ -751,6 +757,22 @@ extern "C" int ptv3_window_attn_varlen_fwd(const void* qkv, const int32_t* win_o
   const double flops = 4.0 * (sum_len_sq > 0 ? sum_len_sq : (double)n_pad * max_seqlen) * c;
   return window_attn_fwd_impl(qkv, win_order, win_inverse, cu_seqlens, num_windows, out, n, n_pad, c, heads,
                               max_seqlen, scale, nullptr, dtype, flops, (hipStream_t)stream);
+}
+
+extern "C" int ptv3_window_attn_train_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,
+                                          const int32_t* cu_seqlens, int num_windows, void* out, float* lse, int64_t n,
+                                          int64_t n_pad, int c, int heads, int patch, float scale, double sum_len_sq,
+                                          int dtype, void* stream) {
+  PTV3_REQUIRE(heads > 0 && c % heads == 0, "window_attn_train: c=%d not divisible by heads=%d", c, heads);
+  PTV3_REQUIRE(patch >= 1 && patch <= 16384, "window_attn_train: patch %d outside [1,16384]", patch);
+  PTV3_REQUIRE(cu_seqlens != nullptr || n_pad % patch == 0, "window_attn_train: n_pad=%lld is not a multiple of patch=%d",
+               (long long)n_pad, patch);
+  PTV3_REQUIRE(lse != nullptr, "window_attn_train: lse (n_pad x heads floats) is required");
+  PTV3_REQUIRE(dtype == PTV3_F32 || dtype == PTV3_BF16, "window_attn_train: bad dtype %d", dtype);
+  const int nwin = cu_seqlens ? num_windows : (int)(n_pad / patch);
+  const double flops = 4.0 * (cu_seqlens && sum_len_sq > 0 ? sum_len_sq : (double)n_pad * patch) * c;
+  return window_attn_fwd_impl(qkv, win_order, win_inverse, cu_seqlens, nwin, out, n, n_pad, c, heads, patch, scale,
+                              nullptr, dtype, flops, (hipStream_t)stream, lse);
 }
 
 extern "C" int ptv3_window_attn_rpe_fwd(const void* qkv, const int32_t* win_order, const int32_t* win_inverse,

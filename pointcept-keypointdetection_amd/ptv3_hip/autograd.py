@@ -246,17 +246,17 @@ class WindowAttentionFn(Function):
     @staticmethod
     def forward(ctx, qkv, win_order, win_inverse, heads, patch, scale, cu=None):
         qkv = qkv.contiguous()
-        out = ops.window_attention_any(qkv, win_order, win_inverse, heads, patch, scale, cu)
-        ctx.save_for_backward(qkv, out, win_order, win_inverse, cu)
+        out, lse = ops.window_attention_train(qkv, win_order, win_inverse, heads, patch, scale, cu)
+        ctx.save_for_backward(qkv, out, lse, win_order, win_inverse, cu)
         ctx.cfg = (heads, patch, scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, out, win_order, win_inverse, cu = ctx.saved_tensors
+        qkv, out, lse, win_order, win_inverse, cu = ctx.saved_tensors
         heads, patch, scale = ctx.cfg
-        return (ops.window_attention_bwd(qkv, out, dout.contiguous(), win_order, win_inverse, heads, patch, scale, cu),
-                None, None, None, None, None, None)
+        return (ops.window_attention_train_bwd(qkv, out, dout.contiguous(), lse, win_order, win_inverse, heads, patch,
+                                               scale, cu), None, None, None, None, None, None)
 
 
 class WindowAttentionDropFn(Function):
@@ -458,14 +458,14 @@ class BlockFn(Function):
         f1 = ops.layernorm(c2, f32(ln0_g), f32(ln0_b), eps, res=feat)
         t3 = ops.layernorm(f1, f32(n1_g), f32(n1_b), eps)
         qkv = _lin_fwd(t3, w_qkv[0], qkv_b)
-        a = ops.window_attention_any(qkv, wo, wi, heads, patch, scale, cu)
+        a, lse = ops.window_attention_train(qkv, wo, wi, heads, patch, scale, cu)
         f2 = _branch_add(f1, a, w_proj[0], proj_b, mask1)
         t5 = ops.layernorm(f2, f32(n2_g), f32(n2_b), eps)
         h0 = _lin_fwd(t5, w_fc1[0], fc1_b)
         h = ops.affine_act(h0, None, None, ops.ACT_GELU)
         out = _branch_add(f2, h, w_fc2[0], fc2_b, mask2)
         ctx.save_for_backward(xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2,
-                              conv_w, ln0_g, n1_g, n2_g, cu)
+                              conv_w, ln0_g, n1_g, n2_g, cu, lse)
         ctx.cast = (w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2)
         ctx.cfg = (heads, patch, scale, eps, same)
         return out
@@ -473,7 +473,7 @@ class BlockFn(Function):
     @staticmethod
     def backward(ctx, dout):
         (xin, c1, c2, f1, t3, qkv, a, f2, t5, h0, h, nbr, row_order, wo, wi, mask1, mask2, conv_w, ln0_g, n1_g,
-         n2_g, cu) = ctx.saved_tensors
+         n2_g, cu, lse) = ctx.saved_tensors
         w_conv, w_lin, w_qkv, w_proj, w_fc1, w_fc2 = ctx.cast
         heads, patch, scale, eps, same = ctx.cfg
         dt = dout.dtype
@@ -490,7 +490,7 @@ class BlockFn(Function):
         # ---- attention branch
         dp = df2 if mask1 is None else df2 * mask1
         da, dW_proj, db_proj = _lin_bwd(dp, a, w_proj, gran)
-        dqkv = ops.window_attention_bwd(qkv, a, da.contiguous(), wo, wi, heads, patch, scale, cu)
+        dqkv = ops.window_attention_train_bwd(qkv, a, da.contiguous(), lse, wo, wi, heads, patch, scale, cu)
         dt3, dW_qkv, db_qkv = _lin_bwd(dqkv, t3, w_qkv, gran)
         df1, dg1, db1 = ops.layernorm_bwd(f1, dt3, f32(n1_g), eps, add=df2)
         # ---- xCPE branch
@@ -579,8 +579,11 @@ class BlockNativeFn(Function):
         nb = lib.ptv3_block_train_workspace_bytes(ctypes.byref(b), 0)
         wsb = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
         b.workspace, b.workspace_bytes = wsb.data_ptr(), nb
+        lse = torch.empty(wo.shape[0] * int(heads), dtype=torch.float32, device=dev)   # the attention's log-sum-exp rows
+        b.attn_lse = lse.data_ptr()
         lib.check(lib.ptv3_block_train_fwd(ctypes.byref(b), ops._stream()), "ptv3_block_train_fwd")
         ctx.save_for_backward(feat, xin, nbr, row_order, wo, wi, cu, mask1, mask2)
+        ctx.lse = lse
         ctx.block, ctx.flat, ctx.keep = b, flat, (ws, conv_w, (conv_b, lin_b, qkv_b, proj_b, fc1_b, fc2_b, ln0_g, ln0_b,
                                                                 n1_g, n1_b, n2_g, n2_b))
         ctx.shapes = (n, c, hidden, kvol, conv_w.shape)
@@ -613,7 +616,7 @@ class BlockNativeFn(Function):
         lib.check(lib.ptv3_block_train_bwd(ctypes.byref(b), ops._stream()), "ptv3_block_train_bwd")
         (dw_conv, dw_lin, dw_qkv, dw_proj, dw_fc1, dw_fc2, db_conv, db_lin, db_qkv, db_proj, db_fc1, db_fc2, dln0, dln1,
          dln2) = parts
-        ctx.flat = None
+        ctx.flat = ctx.lse = None
         return (dfeat, dconv, dw_conv.view(conv_shape), db_conv, dw_lin.view(c, c), db_lin, dln0[:c], dln0[c:], dln1[:c],
                 dln1[c:], dw_qkv.view(3 * c, c), db_qkv, dw_proj.view(c, c), db_proj, dln2[:c], dln2[c:],
                 dw_fc1.view(hidden, c), db_fc1, dw_fc2.view(c, hidden), db_fc2, None, None, None, None, None, None, None,

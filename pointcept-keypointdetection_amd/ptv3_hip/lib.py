@@ -32,7 +32,7 @@ class BlockTrain(ctypes.Structure):
                                   "dw_conv", "dw_lin", "dw_qkv", "dw_proj", "dw_fc1", "dw_fc2",
                                   "db_conv", "db_lin", "db_qkv", "db_proj", "db_fc1", "db_fc2",
                                   "dln0", "dln1", "dln2", "workspace")] +
-                [("workspace_bytes", c_size_t)])
+                [("workspace_bytes", c_size_t), ("attn_lse", P)])
 
 
 # name -> (restype, argtypes); must list every symbol include/ptv3_hip.h declares
@@ -95,6 +95,10 @@ SIGNATURES = {
                                      c_size_t, P]),
     "ptv3_window_attn_varlen_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
                                             c_int, P, c_size_t, P]),
+    "ptv3_window_attn_train_fwd": (c_int, [P, P, P, P, c_int, P, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
+                                           c_double, c_int, P]),
+    "ptv3_window_attn_train_bwd": (c_int, [P, P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,
+                                           c_int, P, c_size_t, P]),
     "ptv3_window_attn_drop_fwd": (c_int, [P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float, c_float,
                                           c_uint32, c_int, P]),
     "ptv3_window_attn_drop_bwd": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int64, c_int, c_int, c_int, c_float,

@@ -182,6 +182,47 @@ def window_attention_any(qkv, win_order, win_inverse, heads, patch, scale, cu_se
     return window_attention_varlen(qkv, win_order, win_inverse, cu_seqlens, heads, patch, scale, sum_len_sq)
 
 
+def window_attention_train(qkv, win_order, win_inverse, heads, patch, scale, cu_seqlens=None, sum_len_sq=0.0):
+    """The training forward: window_attention_any() that also returns the log-sum-exp rows (n_pad, heads) fp32 the
+    backward would otherwise recompute."""
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(win_order, "win_order", torch.int32, 1)
+    _chk(win_inverse, "win_inverse", torch.int32, 1)
+    _chk(cu_seqlens, "cu_seqlens", torch.int32, 1)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    if win_inverse.shape[0] != n:
+        raise RuntimeError("window_attention_train: shape mismatch")
+    out = torch.empty((n, c), dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty((win_order.shape[0], int(heads)), dtype=torch.float32, device=qkv.device)
+    nwin = cu_seqlens.numel() - 1 if cu_seqlens is not None else 0
+    lib.check(lib.ptv3_window_attn_train_fwd(_p(qkv), _p(win_order), _p(win_inverse), _p(cu_seqlens), nwin, _p(out),
+                                             _p(lse), n, win_order.shape[0], c, int(heads), int(patch), float(scale),
+                                             float(sum_len_sq), _dt(qkv), _stream()), "ptv3_window_attn_train_fwd")
+    return out, lse
+
+
+def window_attention_train_bwd(qkv, out, dout, lse, win_order, win_inverse, heads, patch, scale, cu_seqlens=None):
+    _chk(qkv, "qkv", (torch.float32, torch.bfloat16), 2)
+    _chk(out, "out", qkv.dtype, 2)
+    _chk(dout, "dout", qkv.dtype, 2)
+    _chk(lse, "lse", torch.float32, 2)
+    _chk(cu_seqlens, "cu_seqlens", torch.int32, 1)
+    n, c3 = qkv.shape
+    c = c3 // 3
+    n_pad = win_order.shape[0]
+    if tuple(lse.shape) != (n_pad, int(heads)):
+        raise RuntimeError("window_attention_train_bwd: lse must be (n_pad, heads)")
+    dqkv = torch.empty_like(qkv)
+    nb = lib.ptv3_window_attn_bwd_workspace_bytes(n, n_pad, c, int(heads), _dt(qkv))
+    ws = _ws(nb, qkv.device)
+    nwin = cu_seqlens.numel() - 1 if cu_seqlens is not None else 0
+    lib.check(lib.ptv3_window_attn_train_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(win_order), _p(win_inverse),
+                                             _p(cu_seqlens), nwin, _p(dqkv), n, n_pad, c, int(heads), int(patch),
+                                             float(scale), _dt(qkv), _p(ws), nb, _stream()), "ptv3_window_attn_train_bwd")
+    return dqkv
+
+
 def window_attention_drop(qkv, win_order, win_inverse, heads, patch, scale, p_drop, seed, cu_seqlens=None):
     """Training forward with attention dropout (:203 / :211): softmax over all pairs, kept pairs / (1 - p_drop) into the
     value sum; the keep mask is a hash of (query slot, head, key slot, seed) - see drop_keep_mask()."""
