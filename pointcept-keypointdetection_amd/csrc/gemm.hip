@@ -920,10 +920,11 @@ static bool use_conv_tile(int64_t m, int cin, int cout, int kvol, int dtype, int
   if (splits > 1) {
     // the deep levels of a 100k-point scene (10^2 .. 10^4 sites at C = 128 .. 512): the K range of every split-K slab
     // through the 256-point tile (128 channels: more workgroups) instead of four 64-point tiles re-reading W -
-    // 22 -> ~11 us per convolution, the slabs and their consumers unchanged.  PTV3_CONV_TILE_SPLIT=0: off
-    const char* se = getenv("PTV3_CONV_TILE_SPLIT");
+    // 22 -> 17 us per convolution, the slabs and their consumers unchanged
+    // bf16 only by default: with the exact-fp32 matrix path (a quarter of the rate) the forward measured 5.96 vs 5.90 ms
+    const char* se = getenv("PTV3_CONV_TILE_SPLIT");   // 0: off, 1: both dtypes (tests), unset: bf16
     *bn_out = 128;
-    return cout % 8 == 0 && !(se && atoi(se) == 0);
+    return cout % 8 == 0 && (se ? atoi(se) != 0 : dtype == PTV3_BF16);
   }
   const int bn = (dtype == PTV3_BF16 && cout >= 256) ? 256 : 128;
   *bn_out = bn;
