@@ -188,6 +188,37 @@ def test_window_attention_backward(dev, sizes, C, H, K):
     _close(qb.grad, qr.grad, tol=5e-2, what="dqkv bf16")
 
 
+@pytest.mark.parametrize("sizes,C,H,K", [([300, 200], 32, 2, 64), ([2100], 64, 4, 1024), ([130, 77, 300], 64, 2, 50)])
+def test_window_attention_train_forward_leaves_the_log_sum_exp(dev, sizes, C, H, K):
+    """ptv3_window_attn_train_fwd: the same output as the eval entry point plus, per (padded slot, head), the log2-domain
+    log-sum-exp of the scaled scores - checked against torch.logsumexp on the gathered q, k; the backward that takes it
+    (ptv3_window_attn_train_bwd) against the one that recomputes it."""
+    from ptv3_hip import ops
+    n, order, inverse, pad, unpad = _attn_setup(sizes, K, seed=C + K)
+    g = torch.Generator().manual_seed(K + 1)
+    qkv = torch.randn(n, 3 * C, generator=g)
+    dout = torch.randn(n, C, generator=g)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    wo, wi = ops.window_maps(t(order).to(dev), t(inverse).to(dev), t(pad).to(dev), t(unpad).to(dev))
+    scale = (C // H) ** -0.5
+    x = qkv[t(order)[t(pad)]]
+    q, k, _ = x.reshape(-1, K, 3, H, C // H).permute(2, 0, 3, 1, 4).unbind(dim=0)          # (W, H, K, D)
+    want = torch.logsumexp((q * scale) @ k.transpose(-2, -1), dim=-1) / np.log(2.0)            # (W, H, K)
+    want = want.permute(0, 2, 1).reshape(-1, H)                                                 # (n_pad, H)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        qd = qkv.to(dev, dtype)
+        out, lse = ops.window_attention_train(qd, wo, wi, H, K, scale)
+        assert torch.equal(out, ops.window_attention(qd, wo, wi, H, K, scale))
+        ref = want if dtype == torch.float32 else \
+            (torch.logsumexp((q.bfloat16().float() * scale) @ k.bfloat16().float().transpose(-2, -1), dim=-1)
+             / np.log(2.0)).permute(0, 2, 1).reshape(-1, H)
+        assert (lse.cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+        d1 = ops.window_attention_train_bwd(qd, out, dout.to(dev, dtype), lse, wo, wi, H, K, scale)
+        d0 = ops.window_attention_bwd(qd, out, dout.to(dev, dtype), wo, wi, H, K, scale)
+        gs = d0.float().abs().max().item()
+        assert (d1.float() - d0.float()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2e-2) * gs
+
+
 @pytest.mark.parametrize("sizes,C,H,K,p", [([300, 200], 32, 2, 64, 0.1), ([1500], 64, 4, 256, 0.25), ([400], 128, 2, 128, 0.5),
                                            ([2100], 32, 2, 1024, 0.1)])
 def test_window_attention_dropout_forward_and_backward(dev, sizes, C, H, K, p):
